@@ -1,0 +1,111 @@
+/*
+ * mc_oracle.h -- CPU ORACLE for the marching-cubes hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's algorithm
+ * (raineyeh/Marching-Cube-for-Implicit-Surfaces: Source/evaluator.cpp,
+ * Source/marching.cpp, Source/marching_lookup.h).  Every function cites the
+ * reference file:line it follows.  Nothing under oracle/ is part of the
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it, and only as the checker / the timed CPU baseline.  The
+ * product path (libmc_hip.so) never links, loads or calls this code.
+ *
+ * Parity pin: the reference itself cannot be built in this image (both hot
+ * path TUs #include <windows.h>, marching.cpp:3 / evaluator.cpp:2, and the
+ * rules forbid stand-in headers), so the oracle is pinned against
+ *   - the reference's own tokenizer self-test (evaluator.h:67-77),
+ *   - the known-answer counts and FNV-1a fingerprints of per-cell cube codes
+ *     and triangle soup that SURVEY.md section 4 recorded from the unmodified
+ *     reference (10 configurations), and
+ *   - the sha256 of the case tables, re-checked
+ *     against marching_lookup.h compiled in place by oracle/Makefile (_ref).
+ * See tests/test_oracle_pins.py.
+ */
+#ifndef MC_ORACLE_H
+#define MC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How `^` is evaluated (reference: evaluator.cpp:133, pow(float,float) -> powf). */
+enum {
+    ORC_POW_LIBM = 0,  /* faithful: libm powf, what the reference executes            */
+    ORC_POW_EXACT = 1  /* device-matching: constant integer exponents |n|<=16 become   */
+                       /* an IEEE product chain, everything else (float)pow(double)    */
+};
+
+/* token types, evaluator.h:21 */
+enum { ORC_OP = 0, ORC_NUM, ORC_VAR, ORC_BRAC_O, ORC_BRAC_C, ORC_NEG };
+
+typedef struct {
+    int type;  /* ORC_* */
+    char ch;   /* operator / bracket / variable character */
+    float num; /* ORC_NUM: strtof of the literal (evaluator.cpp:82 does stof per call) */
+} orc_token;
+
+typedef struct {
+    int n;
+    int cap;
+    orc_token *tok;
+} orc_expr;
+
+/* evaluator.cpp:139-237.  Returns 1 (accepted) or 0 (rejected), like the reference. */
+int orc_tokenize(const char *eq, orc_expr *out);
+void orc_expr_free(orc_expr *e);
+
+/* evaluator.cpp:53-107 + :22-48 + :111-136.  Returns 0 on success, -1 when the
+ * reference would read below its stacks (undefined behaviour there). */
+int orc_evaluate(const orc_expr *e, float x, float y, float z, int pow_mode, float *out);
+
+/* marching.cpp:372-383: number of lower-corner iterations per axis for a step,
+ * and the shared coordinate table c[0..n1] (c[i+1] = c[i] + step in float). */
+int orc_cells_per_axis(float step);
+int orc_axis_coords(float step, float *c, int cap);
+
+enum {
+    ORC_WANT_CODES = 1,   /* raw cube_code per cell (before the ambiguity redirect) */
+    ORC_WANT_SOUP = 2,    /* 9 floats / triangle, emission order                    */
+    ORC_WANT_NORMALS = 4  /* 9 floats / triangle, gradient normals   */
+};
+
+typedef struct {
+    int n1;              /* cells per axis */
+    uint64_t n_cells;    /* cells swept (n1*n1*(z_end-z_begin)) */
+    uint64_t n_active;   /* cells with code not in {0,255} */
+    uint64_t n_tris;
+    uint64_t n_amb;      /* cells whose code is an ambiguous case */
+    uint64_t n_flipped;  /* ... of which the alternative row was taken */
+    uint64_t fnv_codes;  /* FNV-1a 64 of the code bytes, sweep order */
+    uint64_t fnv_soup;   /* FNV-1a 64 of the little-endian float32 soup bytes */
+    uint8_t *codes;      /* n_cells bytes or NULL */
+    float *soup;         /* 9*n_tris floats or NULL */
+    float *normals;      /* 9*n_tris floats or NULL */
+} orc_mesh;
+
+/* marching.cpp:368-384 (sweep) + :456-595 (calculate_step) + :437-446 (interp)
+ * + :209-224 (scaling).  z_begin/z_end select a contiguous range of cell layers
+ * (pass 0,-1 for all).  nthreads<=1 -> the reference's single-threaded sweep;
+ * >1 -> z layers are processed by that many threads and concatenated in order
+ * (results identical).  Returns 0, or -1 parse error, -2 evaluation underflow,
+ * -3 bad step, -4 out of memory. */
+int orc_march(const char *eq, float step, float iso, const float scale[3], int pow_mode,
+              int want, int z_begin, int z_end, int nthreads, orc_mesh *out);
+void orc_mesh_free(orc_mesh *m);
+
+/* FNV-1a 64 (offset 1469598103934665603, prime 1099511628211), SURVEY.md section 4. */
+uint64_t orc_fnv1a(const void *p, size_t n, uint64_t h);
+
+/* packed case tables (include/mc_tables_data.h) exposed for the table tests */
+const uint64_t *orc_tri_rows(void);
+const uint8_t *orc_tri_counts(void);
+const uint8_t *orc_amb_faces(void);
+const uint16_t *orc_face_corners(void);
+const uint8_t *orc_edge_corners(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
