@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- marching-cubes voxel sweep throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--equation EQ] [--no-cpu-baseline]
+
+One "step" = one full pass of the hot path (classify -> scan -> emit, normals on) over the
+headline workload of BASELINE.json: the sphere SDF x^2+y^2+z^2-1 on a 1024^3 grid
+(grid_res 1024 -> 1025^3 cells swept, like the reference: marching.cpp:372-383), f analytic,
+nothing to upload, all buffers resident in HBM.  With N > 1 (launched by torch.distributed.run,
+one process per GPU) the SAME grid is sharded along Z into N contiguous slabs (strong scaling);
+the only exchange is an RCCL all-gather of the per-rank triangle counts, from which every rank
+derives its offset in the global triangle list (analytic f needs no halo: DESIGN.md).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (classify), measured live
+with HIP events on the library's stream; `pipeline` gives the same figure for the whole
+classify+scan+emit chain against SURVEY 8d's 2*C + 72*T bytes.  `cpu_baseline` times the CPU
+oracle (oracle/, a port of the reference, all host cores) on a bounded Z-slab of the same
+workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(eq, step, n1, budget_s=15.0):
+    """Oracle (port of the reference) on the host cores, on a bounded slab of the same grid."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import pyoracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    mid = n1 // 2
+    t0 = time.perf_counter()
+    probe_layers = max(1, min(cores, n1 - mid))
+    orc.march(eq, step, 0.0, pow_mode=orc.POW_LIBM, want=orc.WANT_SOUP, z_begin=mid, z_end=mid + probe_layers,
+              nthreads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    layers = int(max(probe_layers, min(n1 - mid, budget_s / dt * probe_layers)))
+    t0 = time.perf_counter()
+    m = orc.march(eq, step, 0.0, pow_mode=orc.POW_LIBM, want=orc.WANT_SOUP, z_begin=mid, z_end=mid + layers,
+                  nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(m.n_cells / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/mc_oracle.c (libm powf, {cores} threads) on cell layers z=[{mid},{mid + layers}) of the "
+                      f"same {n1}^3-cell grid: {m.n_cells} cells, {m.n_tris} triangles in {dt:.2f} s",
+            "mtris_per_s": round(m.n_tris / dt / 1e6, 5)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid-res", type=int, default=1024)
+    ap.add_argument("--equation", default="x^2+y^2+z^2-1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-normals", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mc_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+
+    eq = args.equation
+    step = float(np.float32(2.0) / np.float32(args.grid_res))
+    n1 = mc_amd.cells_per_axis(step)
+    zb, ze = mc_amd.shard_layers(n1, world, rank)
+    flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
+    ctx = mc_amd.Context(local_rank)
+    counts_dev = torch.zeros(world, dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def one_step():
+        r = ctx.march(eq, step, 0.0, flags=flags, z_begin=zb, z_end=ze)
+        if world > 1:  # the path's one real exchange: per-rank triangle counts -> global offsets
+            mine = torch.tensor([r.n_tris], dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(counts_dev, mine)
+        return r
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    kt = np.zeros(4)
+    for _ in range(args.steps):
+        r = one_step()
+        kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt /= max(args.steps, 1)
+
+    stats = torch.tensor([elapsed, float(r.n_cells), float(r.n_tris), *kt], dtype=torch.float64)
+    if world > 1:
+        stats = stats.cuda()
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        cells, tris = float(sm[1]), float(sm[2])
+        kmax = mx[3:].cpu().numpy()
+        offsets, total = mc_amd.exclusive_offsets(counts_dev.cpu().tolist())
+        assert total == int(tris)
+    else:
+        cells, tris = float(r.n_cells), float(r.n_tris)
+        kmax = kt
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        ms_cls, ms_scan, ms_emit, ms_tot = (float(x) for x in kmax)
+        # algorithmic bytes (SURVEY 8d / DESIGN.md): classify writes 1 B per cell; emit reads 1 B per cell
+        # and writes 72 B per triangle.  Per launch on this rank's slab (N=1: the whole grid).
+        c_launch, t_launch = cells / world, tris / world
+        cls_bytes = 1.0 * c_launch
+        pipe_bytes = 2.0 * c_launch + 72.0 * t_launch
+        cls_gbs = cls_bytes / (ms_cls * 1e-3) / 1e9 if ms_cls > 0 else 0.0
+        pipe_gbs = pipe_bytes / (ms_tot * 1e-3) / 1e9 if ms_tot > 0 else 0.0
+        out = {
+            "metric": "Mvoxels/s", "value": round(cells / (elapsed / args.steps) / 1e6, 2), "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sphere SDF {eq}, grid_res {args.grid_res} ({n1}^3 cells), iso 0, scale 1, "
+                                   f"normals {'off' if args.no_normals else 'on'}",
+                       "cells": int(cells), "triangles": int(tris),
+                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU"},
+            "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
+            "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
+                          "gpu_total": round(ms_tot, 4)},
+            "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(cls_bytes)},
+            "pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(pipe_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(pipe_bytes),
+                         "formula": "2*C + 72*T (SURVEY 8d)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eq, step, n1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

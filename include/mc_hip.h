@@ -1,0 +1,141 @@
+/*
+ * mc_hip.h -- C ABI of libmc_hip.so, the MI355X (gfx950) marching-cubes hot path.
+ *
+ * Drop-in boundary for ONE path of raineyeh/Marching-Cube-for-Implicit-Surfaces:
+ * the full-sweep branch of Marching::recalculate() and everything it calls
+ * (Source/marching.cpp:368-384 -> calculate_step :456-595 -> Evaluator::evaluate
+ * Source/evaluator.cpp:53-107, tables Source/marching_lookup.h).  The reference
+ * has no FFI; its boundary is the public surface of `class Marching`
+ * (Source/marching.h:72-157) and `class Evaluator` (Source/evaluator.h:24-86).
+ * Each entry point below names the reference member it replaces.  A C++ facade
+ * with the reference's class and method names is include/mc_marching.hpp; the
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Plain C types only: pointers, sizes, POD structs.  All compute runs on the
+ * GPU (hand-written HIP kernels, specialised per equation with hiprtc); there
+ * is no CPU fallback -- every call fails with MC_ERR_HIP when no gfx950 device
+ * or no HIP runtime is present.
+ */
+#ifndef MC_HIP_H
+#define MC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+
+/* Status codes (the reference returns bool / throws std::exception without text:
+ * evaluator.cpp:10-13, marching.cpp:226-238). */
+enum {
+    MC_OK = 0,
+    MC_ERR_PARSE = 1,     /* Evaluator::set_equation would return false (evaluator.cpp:15-17)      */
+    MC_ERR_EVAL = 2,      /* tokenizer accepts but Evaluator::evaluate reads below its stacks --   */
+                          /* undefined behaviour in the reference (e.g. "x+"), refused here        */
+    MC_ERR_STEP = 3,      /* Marching::set_grid_step_size would return false (marching.cpp:226)    */
+    MC_ERR_ARG = 4,       /* null pointer / bad range / bad flag                                    */
+    MC_ERR_HIP = 5,       /* HIP runtime, hiprtc or device error; text in mc_last_error()          */
+    MC_ERR_NOMEM = 6,     /* device or host allocation failed                                       */
+    MC_ERR_OVERFLOW = 7   /* more than 2^32-1 triangles in one slab: split with z_begin/z_end      */
+};
+
+/* Flags for mc_params.flags */
+enum {
+    MC_FLAG_NORMALS = 1u,      /* fill the normal half of each vertex (gradient of f);  */
+                               /* without it normals are written as 0                                 */
+    MC_FLAG_KEEP_CODES = 2u,   /* keep the per-cell cube codes readable through mc_copy_codes()       */
+    MC_FLAG_NO_EMIT = 4u,      /* classify + count only (cube codes and triangle count, no vertices)  */
+    MC_FLAG_TILE1 = 8u         /* diagnostic: classify with row tiles of height 1 (no sample reuse)   */
+};
+
+typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */
+
+/* Parameters of one sweep.  Field <- reference setter it mirrors. */
+typedef struct mc_params {
+    const char *equation; /* Evaluator::set_equation(string)            evaluator.cpp:15            */
+    float step;           /* Marching::set_grid_step_size(float)        marching.cpp:226, [0.001,.5] */
+    float iso;            /* Marching::set_surface_constant(float)      marching.cpp:149            */
+    float scale[3];       /* Marching::set_scaling_{x,y,z}(float)       marching.cpp:240-251        */
+    uint32_t flags;       /* MC_FLAG_*                                                              */
+    int32_t z_begin;      /* first cell layer of this slab (0-based); Z-sharding across GPUs        */
+    int32_t z_end;        /* one past the last layer; <0 means "to the end" (whole grid = 0,-1)     */
+} mc_params;
+
+/* Result of one sweep.  Device buffers are owned by the context and stay valid
+ * until the next mc_march()/mc_context_destroy() on it (the reference's
+ * Poly_Data pointer has the same lifetime rule: marching.cpp:293-305, 656-658). */
+typedef struct mc_result {
+    int32_t cells_per_axis; /* n1 = loop trip count of marching.cpp:375-377 (grid_res N -> N+1)     */
+    int32_t z_begin, z_end; /* slab actually swept                                                   */
+    uint64_t n_cells;       /* n1*n1*(z_end-z_begin)                                                */
+    uint64_t n_active;      /* cells whose cube code is neither 0 nor 255                            */
+    uint64_t n_tris;        /* triangles emitted, reference emission order (z, y, x, table order)    */
+    const float *d_vertices;/* device: n_tris*3 vertices * 6 floats {x,y,z,nx,ny,nz}; 72 B/triangle  */
+    const uint8_t *d_codes; /* device: raw cube codes, row pitch code_pitch, (z-z_begin, y) rows     */
+    uint64_t code_pitch;    /* bytes between consecutive (z,y) rows of d_codes                       */
+    float ms_classify;      /* GPU time of the classify kernel (hipEvent, ms)                        */
+    float ms_scan;          /* ... of the triangle-count scan                                        */
+    float ms_emit;          /* ... of the emit kernel                                                */
+    float ms_total;         /* first kernel start -> last kernel end                                 */
+} mc_result;
+
+/* -- library ------------------------------------------------------------- */
+int mc_abi_version(void);
+const char *mc_last_error(void);  /* thread-local text of the last failing call ("" if none) */
+int mc_device_count(void);        /* gfx950 devices visible to HIP; 0 when none / no driver   */
+
+/* -- expression layer (Evaluator) ---------------------------------------- */
+/* Evaluator::set_equation / tokenize accept-reject only (evaluator.cpp:139-237): 1 accept, 0 reject. */
+int mc_expr_check(const char *equation);
+/* Compile to the evaluation DAG the reference's two-stack walk performs (evaluator.cpp:22-107).
+ * Returns MC_OK / MC_ERR_PARSE / MC_ERR_EVAL.  Pure host work, no GPU needed. */
+int mc_expr_validate(const char *equation);
+/* Writes the generated device function (HIP source text of mc_f) into buf; returns its full length.
+ * Lets a maintainer audit the evaluation order (e.g. x-y-z becomes x-(y-z)). */
+size_t mc_expr_dump(const char *equation, char *buf, size_t cap);
+/* Diagnostic: interpret the compiled DAG on the host for ONE point (same op order and float ops
+ * as the device code, P1 power rule).  Used by the CPU-side tests of the compiler; the product
+ * never calls it -- Evaluator::evaluate maps to mc_eval_points (GPU). */
+int mc_expr_debug_eval_host(const char *equation, float x, float y, float z, float *out);
+
+/* Specialise the kernels for `equation` with hiprtc (gfx950 code object) WITHOUT touching a GPU:
+ * pre-populates the on-disk cache named by $MC_JIT_CACHE and lets a build machine check that the
+ * generated code compiles.  code_size (optional) receives the code-object size in bytes. */
+int mc_jit_precompile(const char *equation, size_t *code_size);
+
+/* -- context -------------------------------------------------------------- */
+int mc_context_create(int device, mc_context **out);
+void mc_context_destroy(mc_context *ctx);
+
+/* Evaluator::evaluate(x,y,z) for n points (evaluator.cpp:53): xyz = n*3 host floats, out = n host floats. */
+int mc_eval_points(mc_context *ctx, const char *equation, const float *xyz, size_t n, float *out);
+
+/* -- the sweep: Marching::recalculate() full-sweep branch (marching.cpp:368-384) ---------- */
+int mc_march(mc_context *ctx, const mc_params *p, mc_result *res);
+/* north-star convenience: march(equation, grid_res, iso) with step = 2.0f/grid_res, scale 1. */
+int mc_march_simple(mc_context *ctx, const char *equation, int grid_res, float iso, uint32_t flags, mc_result *res);
+
+/* Copy results of the last mc_march() to host memory.
+ * mc_copy_vertices: n_tris*18 floats (positions+normals interleaved).
+ * mc_copy_soup:     n_tris*9 floats, positions only -- the reference's pre-dedup triangle soup
+ *                   (Step_Data::intersect_coord[tri_vlist[k]], marching.cpp:586-594).
+ * mc_copy_codes:    n_cells bytes, compact, sweep order x-fastest (needs MC_FLAG_KEEP_CODES). */
+int mc_copy_vertices(mc_context *ctx, float *host, uint64_t max_tris);
+int mc_copy_soup(mc_context *ctx, float *host, uint64_t max_tris);
+int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
+
+/* marching.cpp:372-377: trip count of `for (v=-1.0f; v <= (float)(1.0+0.5*step); v += step)`. 0 if step rejected. */
+int mc_cells_per_axis(float step);
+
+/* -- steady-state replay (animated iso sweep): capture classify->scan->emit once as a hipGraph
+ *    and replay it with a new iso value per frame (Marching::set_surface_constant + recalculate). */
+int mc_graph_build(mc_context *ctx, const mc_params *p);
+int mc_graph_replay(mc_context *ctx, float iso, mc_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_HIP_H */

@@ -1,0 +1,249 @@
+"""marching-cube-for-implicit-surfaces_amd -- MI355X-native marching-cubes hot path.
+
+Thin ctypes binding of libmc_hip.so (C ABI: include/mc_hip.h).  The compute is
+hand-written HIP for gfx950 inside that library; this module only mirrors the
+reference's operator surface (Evaluator / Marching, Source/evaluator.h:24-86,
+Source/marching.h:72-157) for tests and bench.py.  There is no CPU fallback:
+if the library is missing or no GPU is visible, calls raise.
+
+The directory name is not a Python identifier; load it with importlib (see
+mc_amd.py at the repository root, which does exactly that).
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libmc_hip.so"
+
+MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NOMEM, MC_ERR_OVERFLOW = range(8)
+FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1 = 1, 2, 4, 8
+
+# every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
+    "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
+    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_cells_per_axis", "mc_graph_build",
+    "mc_graph_replay",
+]
+
+
+class McParams(C.Structure):
+    _fields_ = [("equation", C.c_char_p), ("step", C.c_float), ("iso", C.c_float), ("scale", C.c_float * 3),
+                ("flags", C.c_uint32), ("z_begin", C.c_int32), ("z_end", C.c_int32)]
+
+
+class McResult(C.Structure):
+    _fields_ = [("cells_per_axis", C.c_int32), ("z_begin", C.c_int32), ("z_end", C.c_int32),
+                ("n_cells", C.c_uint64), ("n_active", C.c_uint64), ("n_tris", C.c_uint64),
+                ("d_vertices", C.c_void_p), ("d_codes", C.c_void_p), ("code_pitch", C.c_uint64),
+                ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float)]
+
+
+class McError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmc_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile libmc_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mc_build", _HERE / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(force=force, verbose=verbose)
+
+
+def lib():
+    """Load libmc_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (no CPU fallback exists)")
+        os.environ.setdefault("MC_JIT_CACHE", str(_HERE / "_jit_cache"))
+        (_HERE / "_jit_cache").mkdir(exist_ok=True)
+        L = C.CDLL(str(LIB_PATH))
+        L.mc_last_error.restype = C.c_char_p
+        L.mc_expr_check.argtypes = [C.c_char_p]
+        L.mc_expr_validate.argtypes = [C.c_char_p]
+        L.mc_expr_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mc_expr_dump.restype = C.c_size_t
+        L.mc_expr_debug_eval_host.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.mc_jit_precompile.argtypes = [C.c_char_p, C.POINTER(C.c_size_t)]
+        L.mc_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mc_context_destroy.argtypes = [C.c_void_p]
+        L.mc_context_destroy.restype = None
+        L.mc_eval_points.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mc_march.argtypes = [C.c_void_p, C.POINTER(McParams), C.POINTER(McResult)]
+        L.mc_march_simple.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_uint32, C.POINTER(McResult)]
+        L.mc_copy_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_copy_soup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_cells_per_axis.argtypes = [C.c_float]
+        L.mc_graph_build.argtypes = [C.c_void_p, C.POINTER(McParams)]
+        L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != MC_OK:
+        raise McError(rc, lib().mc_last_error().decode(errors="replace"))
+
+
+# ---- expression layer (Evaluator) ------------------------------------------------------
+def expr_check(eq: str) -> bool:
+    """Evaluator::set_equation accept/reject (evaluator.cpp:15-17, :139-237)."""
+    return bool(lib().mc_expr_check(eq.encode()))
+
+
+def expr_validate(eq: str) -> int:
+    """MC_OK / MC_ERR_PARSE / MC_ERR_EVAL without raising."""
+    return lib().mc_expr_validate(eq.encode())
+
+
+def expr_dump(eq: str) -> str:
+    n = lib().mc_expr_dump(eq.encode(), None, 0)
+    if n == 0:
+        raise McError(MC_ERR_PARSE, lib().mc_last_error().decode())
+    buf = C.create_string_buffer(n + 1)
+    lib().mc_expr_dump(eq.encode(), buf, n + 1)
+    return buf.value.decode()
+
+
+def expr_debug_eval_host(eq: str, x, y, z) -> float:
+    out = C.c_float()
+    _check(lib().mc_expr_debug_eval_host(eq.encode(), x, y, z, C.byref(out)))
+    return out.value
+
+
+def jit_precompile(eq: str) -> int:
+    """hiprtc-compile the kernels for `eq` (no GPU needed); returns the code-object size."""
+    n = C.c_size_t()
+    _check(lib().mc_jit_precompile(eq.encode(), C.byref(n)))
+    return n.value
+
+
+def cells_per_axis(step) -> int:
+    return lib().mc_cells_per_axis(C.c_float(step))
+
+
+def device_count() -> int:
+    return lib().mc_device_count()
+
+
+class Result:
+    """Host view of one sweep (counts + timings); arrays are fetched on demand."""
+
+    def __init__(self, ctx, r: McResult):
+        self._ctx = ctx
+        for k, _ in McResult._fields_:
+            setattr(self, k, getattr(r, k))
+
+    def vertices(self) -> np.ndarray:
+        """(n_tris, 3, 6) float32: x,y,z,nx,ny,nz."""
+        a = np.empty((self.n_tris, 3, 6), dtype=np.float32)
+        if self.n_tris:
+            _check(lib().mc_copy_vertices(self._ctx._h, a.ctypes.data, self.n_tris))
+        return a
+
+    def soup(self) -> np.ndarray:
+        """(n_tris, 3, 3) float32 positions, the reference's pre-dedup triangle soup."""
+        a = np.empty((self.n_tris, 3, 3), dtype=np.float32)
+        if self.n_tris:
+            _check(lib().mc_copy_soup(self._ctx._h, a.ctypes.data, self.n_tris))
+        return a
+
+    def codes(self) -> np.ndarray:
+        """(n_cells,) uint8 raw cube codes in sweep order (x fastest)."""
+        a = np.empty(self.n_cells, dtype=np.uint8)
+        if self.n_cells:
+            _check(lib().mc_copy_codes(self._ctx._h, a.ctypes.data, self.n_cells))
+        return a
+
+
+class Context:
+    """One GPU: stream, buffers and the cache of equations compiled to kernels."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().mc_context_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().mc_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _params(self, equation, step, iso, scale, flags, z_begin, z_end):
+        p = McParams()
+        p.equation = equation.encode()
+        p.step = step
+        p.iso = iso
+        p.scale = (C.c_float * 3)(*scale)
+        p.flags = flags
+        p.z_begin = z_begin
+        p.z_end = z_end
+        return p
+
+    def march(self, equation, step, iso=0.0, scale=(1.0, 1.0, 1.0), flags=FLAG_NORMALS | FLAG_KEEP_CODES, z_begin=0,
+              z_end=-1) -> Result:
+        """Marching::recalculate() full sweep (marching.cpp:368-384) on the GPU."""
+        p = self._params(equation, step, iso, scale, flags, z_begin, z_end)
+        r = McResult()
+        _check(lib().mc_march(self._h, C.byref(p), C.byref(r)))
+        return Result(self, r)
+
+    def march_grid(self, equation, grid_res, iso=0.0, flags=FLAG_NORMALS | FLAG_KEEP_CODES) -> Result:
+        """north-star form march(equation, grid_res, iso): step = 2.0f/grid_res."""
+        r = McResult()
+        _check(lib().mc_march_simple(self._h, equation.encode(), grid_res, iso, flags, C.byref(r)))
+        return Result(self, r)
+
+    def eval_points(self, equation, pts) -> np.ndarray:
+        """Evaluator::evaluate for many points (evaluator.cpp:53), computed on the GPU."""
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(len(pts), dtype=np.float32)
+        _check(lib().mc_eval_points(self._h, equation.encode(), pts.ctypes.data, len(pts), out.ctypes.data))
+        return out
+
+    def graph_build(self, equation, step, iso=0.0, scale=(1.0, 1.0, 1.0), flags=FLAG_NORMALS, z_begin=0, z_end=-1):
+        p = self._params(equation, step, iso, scale, flags, z_begin, z_end)
+        _check(lib().mc_graph_build(self._h, C.byref(p)))
+
+    def graph_replay(self, iso) -> Result:
+        r = McResult()
+        _check(lib().mc_graph_replay(self._h, iso, C.byref(r)))
+        return Result(self, r)
+
+
+# ---- Z-slab sharding across GPUs (one process per GPU; host logic only) -----------------
+def shard_layers(n_layers: int, world: int, rank: int):
+    """Contiguous near-equal range [z_begin, z_end) of cell layers for `rank`.
+
+    Concatenating the ranks' triangle lists in rank order reproduces the single-GPU /
+    reference emission order, because the sweep is z-major (marching.cpp:375)."""
+    base, rem = divmod(n_layers, world)
+    b = rank * base + min(rank, rem)
+    return b, b + base + (1 if rank < rem else 0)
+
+
+def exclusive_offsets(counts):
+    """Per-rank triangle offsets from the all-gathered per-rank counts."""
+    out, acc = [], 0
+    for c in counts:
+        out.append(acc)
+        acc += int(c)
+    return out, acc

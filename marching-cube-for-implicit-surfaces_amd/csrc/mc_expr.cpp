@@ -1,0 +1,365 @@
+// mc_expr.cpp -- see mc_expr.hpp.  Compile with -ffp-contract=off.
+#include "mc_expr.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+namespace mc {
+
+// ---------------------------------------------------------------- tokenizer
+// Character classes: evaluator.h:37-41.
+static bool is_op(char c) { return c == '+' || c == '-' || c == '*' || c == '/' || c == '^'; }
+static bool is_num(char c) { return (c >= '0' && c <= '9') || c == '.'; }
+static bool is_var(char c) { return (c >= 'x' && c <= 'z') || (c >= 'X' && c <= 'Z'); }
+
+bool tokenize(const std::string& eq_in, std::vector<Token>& out) {
+    out.clear();
+    if (eq_in.empty()) return false;  // evaluator.cpp:141
+    std::string s;
+    s.reserve(eq_in.size());
+    for (char c : eq_in)
+        if (c != ' ') s.push_back(c);  // :147, only U+0020 is stripped
+
+    enum Last { L_NONE, L_OP, L_NUM, L_VAR, L_BO, L_BC } last = L_NONE;
+    bool neg = false;
+    int depth = 0;
+    auto implicit_mul = [&]() { out.push_back({TokType::OP, '*', 0.0f}); };
+
+    for (size_t i = 0; i < s.size(); ++i) {
+        const char c = s[i];
+        // :162 -- a '-' is a SIGN when it is the first character or the previous
+        // character (not token) is '(' or an operator.
+        if (c == '-' && (i == 0 || s[i - 1] == '(' || is_op(s[i - 1]))) {
+            if (neg) return false;  // :163 "--"
+            neg = true;
+            out.push_back({TokType::NEG, 'N', 0.0f});
+            continue;  // :167 -- `last` deliberately unchanged
+        }
+        if (c == '(') {  // :170-178
+            if (last == L_VAR || last == L_NUM || last == L_BC) implicit_mul();
+            out.push_back({TokType::BRAC_O, c, 0.0f});
+            ++depth;
+            last = L_BO;
+        } else if (c == ')') {  // :179-185
+            if (neg || last == L_BO || last == L_OP) return false;
+            if (depth == 0) return false;
+            out.push_back({TokType::BRAC_C, c, 0.0f});
+            --depth;
+            last = L_BC;
+        } else if (is_op(c)) {  // :186-191 (a trailing operator IS accepted)
+            if (neg || last == L_BO || last == L_OP || last == L_NONE) return false;
+            out.push_back({TokType::OP, c, 0.0f});
+            last = L_OP;
+        } else if (is_num(c)) {  // :192-214
+            if (last == L_VAR || last == L_BC) implicit_mul();
+            bool dot = (c == '.');
+            size_t j = i;
+            while (j + 1 < s.size() && is_num(s[j + 1])) {
+                if (s[j + 1] == '.') {
+                    if (dot) return false;
+                    dot = true;
+                }
+                ++j;
+            }
+            const std::string lit = s.substr(i, j - i + 1);
+            if (lit == ".") return false;  // :210
+            out.push_back({TokType::NUM, '0', std::strtof(lit.c_str(), nullptr)});
+            i = j;
+            last = L_NUM;
+        } else if (is_var(c)) {  // :215-223
+            if (last == L_VAR || last == L_NUM || last == L_BC) implicit_mul();
+            out.push_back({TokType::VAR, c, 0.0f});
+            last = L_VAR;
+        } else {
+            return false;  // :224
+        }
+        neg = false;  // :227
+    }
+    return depth == 0;  // :231
+}
+
+// ------------------------------------------------------------- power rule P1
+float pow_literal_int(float a, int n) {
+    if (n == 0) return 1.0f;
+    const int m = n < 0 ? -n : n;
+    volatile double p = (double)a;
+    volatile double r = p;
+    for (int i = 2; i <= m; ++i) r = r * p;
+    if (n < 0) r = 1.0 / r;
+    return (float)r;
+}
+float pow_general(float a, float b) { return (float)std::pow((double)a, (double)b); }
+
+static bool literal_int_exponent(float b, int& n) {
+    if (!(std::fabs(b) <= 16.0f)) return false;
+    if (b != std::floor(b)) return false;
+    n = (int)b;
+    return true;
+}
+
+// ------------------------------------------------------------------ builder
+namespace {
+
+struct Builder {
+    std::vector<Node> nodes;
+    std::map<std::tuple<int, int, int, uint32_t, int>, int> cse;
+    bool general_pow = false;
+
+    static uint32_t bits(float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    }
+    int intern(const Node& n) {
+        auto key = std::make_tuple((int)n.op, n.a, n.b, bits(n.cval), n.ipow);
+        auto it = cse.find(key);
+        if (it != cse.end()) return it->second;
+        nodes.push_back(n);
+        cse.emplace(key, (int)nodes.size() - 1);
+        return (int)nodes.size() - 1;
+    }
+    int constant(float v) {
+        Node n;
+        n.op = NodeOp::CONST;
+        n.cval = v;
+        return intern(n);
+    }
+    int var(char c) {
+        Node n;
+        if (c == 'x' || c == 'X') { n.op = NodeOp::VARX; n.deps = 1; }
+        else if (c == 'y' || c == 'Y') { n.op = NodeOp::VARY; n.deps = 2; }
+        else { n.op = NodeOp::VARZ; n.deps = 4; }
+        return intern(n);
+    }
+    bool is_const(int id) const { return nodes[id].op == NodeOp::CONST; }
+
+    int neg(int a) {
+        if (is_const(a)) return constant(-nodes[a].cval);
+        Node n;
+        n.op = NodeOp::NEG;
+        n.a = a;
+        n.deps = nodes[a].deps;
+        return intern(n);
+    }
+    // value = a op b  (evaluator.cpp:127-136)
+    int binary(char op, int a, int b) {
+        if (op == '^') {
+            int e;
+            if (is_const(b) && literal_int_exponent(nodes[b].cval, e)) {
+                if (e == 0) return constant(1.0f);  // powf(x, 0) == 1 for every x, NaN included
+                if (e == 1) return a;               // powf(x, 1) == x
+                if (is_const(a)) return constant(pow_literal_int(nodes[a].cval, e));
+                Node n;
+                n.op = NodeOp::POWI;
+                n.a = a;
+                n.ipow = e;
+                n.deps = nodes[a].deps;
+                return intern(n);
+            }
+            if (is_const(a) && is_const(b)) return constant(pow_general(nodes[a].cval, nodes[b].cval));
+            general_pow = true;
+            Node n;
+            n.op = NodeOp::POW;
+            n.a = a;
+            n.b = b;
+            n.deps = nodes[a].deps | nodes[b].deps;
+            return intern(n);
+        }
+        if (is_const(a) && is_const(b)) {
+            volatile float x = nodes[a].cval, y = nodes[b].cval, r = 0.0f;
+            switch (op) {
+            case '+': r = x + y; break;
+            case '-': r = x - y; break;
+            case '*': r = x * y; break;
+            default: r = x / y; break;
+            }
+            return constant(r);
+        }
+        Node n;
+        n.op = op == '+' ? NodeOp::ADD : op == '-' ? NodeOp::SUB : op == '*' ? NodeOp::MUL : NodeOp::DIV;
+        n.a = a;
+        n.b = b;
+        // IEEE add / mul are commutative bit for bit (NaN payloads aside): canonical order helps CSE
+        if ((n.op == NodeOp::ADD || n.op == NodeOp::MUL) && n.a > n.b) std::swap(n.a, n.b);
+        n.deps = nodes[a].deps | nodes[b].deps;
+        return intern(n);
+    }
+};
+
+int precedence(char c) {  // evaluator.cpp:111-124
+    switch (c) {
+    case 'N': return 4;
+    case '^': return 3;
+    case '/': case '*': return 2;
+    case '+': case '-': return 1;
+    default: return 0;
+    }
+}
+
+struct SymStacks {
+    std::vector<char> ops;
+    std::vector<int> vals;
+};
+
+// evaluator.cpp:22-48 on node ids.  false = the reference would read below a stack.
+bool evaluate_op(Builder& B, SymStacks& S) {
+    if (S.ops.empty()) return false;
+    const char op = S.ops.back();
+    S.ops.pop_back();
+    if (is_op(op)) {
+        if (S.vals.empty()) return false;
+        const int val1 = S.vals.back();
+        S.vals.pop_back();
+        if (!S.ops.empty() && precedence(S.ops.back()) > precedence(op))  // :32-37, ONE level
+            if (!evaluate_op(B, S)) return false;
+        if (S.vals.empty()) return false;
+        const int val2 = S.vals.back();
+        S.vals.pop_back();
+        S.vals.push_back(B.binary(op, val2, val1));  // :39
+        return true;
+    }
+    if (op == 'N') {  // :42-46
+        if (S.vals.empty()) return false;
+        S.vals.back() = B.neg(S.vals.back());
+        return true;
+    }
+    return false;  // :47 throw
+}
+
+}  // namespace
+
+CompileStatus compile(const std::string& eq, Program& out, std::string& err) {
+    std::vector<Token> toks;
+    if (!tokenize(eq, toks)) {
+        err = "equation rejected by the tokenizer (Evaluator::set_equation would return false)";
+        return CompileStatus::PARSE;
+    }
+    Builder B;
+    SymStacks S;
+    const char* underflow =
+        "the reference's Evaluator::evaluate would read below its operand/operator stack for this "
+        "equation (undefined behaviour there); refused";
+    for (const Token& t : toks) {  // evaluator.cpp:62-98
+        switch (t.type) {
+        case TokType::NEG: S.ops.push_back('N'); break;
+        case TokType::VAR: S.vals.push_back(B.var(t.ch)); break;
+        case TokType::NUM: S.vals.push_back(B.constant(t.num)); break;
+        case TokType::BRAC_O: S.ops.push_back('('); break;
+        case TokType::BRAC_C:
+            for (;;) {
+                if (S.ops.empty()) { err = underflow; return CompileStatus::EVAL; }
+                if (S.ops.back() == '(') break;
+                if (!evaluate_op(B, S)) { err = underflow; return CompileStatus::EVAL; }
+            }
+            S.ops.pop_back();
+            break;
+        case TokType::OP: S.ops.push_back(t.ch); break;
+        }
+    }
+    while (!S.ops.empty())  // :100-102
+        if (!evaluate_op(B, S)) { err = underflow; return CompileStatus::EVAL; }
+    if (S.vals.empty()) { err = underflow; return CompileStatus::EVAL; }
+    const int root = S.vals.back();  // :105 (anything left below it is never read)
+
+    // keep only what the root reaches, preserving topological order
+    std::vector<char> live(B.nodes.size(), 0);
+    live[root] = 1;
+    for (int i = (int)B.nodes.size() - 1; i >= 0; --i)
+        if (live[i]) {
+            if (B.nodes[i].a >= 0) live[B.nodes[i].a] = 1;
+            if (B.nodes[i].b >= 0) live[B.nodes[i].b] = 1;
+        }
+    std::vector<int> remap(B.nodes.size(), -1);
+    out = Program();
+    out.equation = eq;
+    for (size_t i = 0; i < B.nodes.size(); ++i)
+        if (live[i]) {
+            Node n = B.nodes[i];
+            if (n.a >= 0) n.a = remap[n.a];
+            if (n.b >= 0) n.b = remap[n.b];
+            remap[i] = (int)out.nodes.size();
+            out.nodes.push_back(n);
+        }
+    out.root = remap[root];
+    out.uses_general_pow = false;
+    for (const Node& n : out.nodes)
+        if (n.op == NodeOp::POW) out.uses_general_pow = true;
+    return CompileStatus::OK;
+}
+
+// ------------------------------------------------------------------ codegen
+std::string emit_hip(const Program& p) {
+    std::string s;
+    char buf[256];
+    s += "// generated from: ";
+    for (char c : p.equation) s.push_back((c == '\n' || c == '\r' || c == '\\') ? ' ' : c);
+    s += "\n__device__ __forceinline__ float mc_f(float x, float y, float z) {\n";
+    s += "    (void)x; (void)y; (void)z;\n";
+    auto name = [&](int id) -> std::string {
+        const Node& n = p.nodes[id];
+        if (n.op == NodeOp::VARX) return "x";
+        if (n.op == NodeOp::VARY) return "y";
+        if (n.op == NodeOp::VARZ) return "z";
+        std::snprintf(buf, sizeof buf, "t%d", id);
+        return buf;
+    };
+    for (size_t i = 0; i < p.nodes.size(); ++i) {
+        const Node& n = p.nodes[i];
+        std::string rhs;
+        switch (n.op) {
+        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: continue;
+        case NodeOp::CONST: {
+            uint32_t u;
+            std::memcpy(&u, &n.cval, 4);
+            std::snprintf(buf, sizeof buf, "__uint_as_float(0x%08xu) /* %.9g */", u, (double)n.cval);
+            rhs = buf;
+            break;
+        }
+        case NodeOp::ADD: rhs = name(n.a) + " + " + name(n.b); break;
+        case NodeOp::SUB: rhs = name(n.a) + " - " + name(n.b); break;
+        case NodeOp::MUL: rhs = name(n.a) + " * " + name(n.b); break;
+        case NodeOp::DIV: rhs = name(n.a) + " / " + name(n.b); break;
+        case NodeOp::NEG: rhs = "-" + name(n.a); break;
+        case NodeOp::POW: rhs = "mc_pow_general(" + name(n.a) + ", " + name(n.b) + ")"; break;
+        case NodeOp::POWI:
+            if (n.ipow == 2) rhs = name(n.a) + " * " + name(n.a);
+            else {
+                std::snprintf(buf, sizeof buf, "mc_pow_int<%d>(", n.ipow);
+                rhs = buf + name(n.a) + ")";
+            }
+            break;
+        }
+        s += "    const float " + name((int)i) + " = " + rhs + ";\n";
+    }
+    s += "    return " + name(p.root) + ";\n}\n";
+    return s;
+}
+
+float eval_host(const Program& p, float x, float y, float z) {
+    std::vector<float> v(p.nodes.size());
+    for (size_t i = 0; i < p.nodes.size(); ++i) {
+        const Node& n = p.nodes[i];
+        volatile float a = n.a >= 0 ? v[n.a] : 0.0f, b = n.b >= 0 ? v[n.b] : 0.0f, r = 0.0f;
+        switch (n.op) {
+        case NodeOp::CONST: r = n.cval; break;
+        case NodeOp::VARX: r = x; break;
+        case NodeOp::VARY: r = y; break;
+        case NodeOp::VARZ: r = z; break;
+        case NodeOp::ADD: r = a + b; break;
+        case NodeOp::SUB: r = a - b; break;
+        case NodeOp::MUL: r = a * b; break;
+        case NodeOp::DIV: r = a / b; break;
+        case NodeOp::NEG: r = -a; break;
+        case NodeOp::POW: r = pow_general(a, b); break;
+        case NodeOp::POWI: r = pow_literal_int(a, n.ipow); break;
+        }
+        v[i] = r;
+    }
+    return v[p.root];
+}
+
+}  // namespace mc

@@ -1,0 +1,64 @@
+// mc_expr.hpp -- host-side expression compiler (product code, C++).
+//
+// Replaces the reference's run-time interpreter Evaluator (Source/evaluator.h:24-86,
+// Source/evaluator.cpp:15-237).  The reference re-walks the token list with two
+// explicit stacks for EVERY sample (evaluator.cpp:53-107, ~97 % of its sweep time).
+// Here the same walk is executed ONCE, symbolically, on the host: operands are DAG
+// node ids instead of floats, so the resulting DAG performs exactly the float
+// operations, in exactly the order, the reference's evaluate_op recursion would
+// (right-to-left reduction of equal-precedence chains, unary minus binding
+// tighter than ^, one-level precedence look-ahead: evaluator.cpp:22-48).
+// The DAG is then emitted as a straight-line HIP device function that hiprtc
+// compiles into the classify / emit kernels (mc_kernels.hip).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mc {
+
+enum class TokType : uint8_t { OP, NUM, VAR, BRAC_O, BRAC_C, NEG };
+
+struct Token {
+    TokType type;
+    char ch;    // operator / bracket / variable letter; 'N' for NEG
+    float num;  // NUM: strtof(text) (the reference calls stof per evaluation, evaluator.cpp:82)
+};
+
+// evaluator.cpp:139-237.  true = the reference's tokenize() accepts the string.
+bool tokenize(const std::string& eq, std::vector<Token>& out);
+
+enum class NodeOp : uint8_t { CONST, VARX, VARY, VARZ, ADD, SUB, MUL, DIV, POW, POWI, NEG };
+
+struct Node {
+    NodeOp op;
+    int a = -1, b = -1;  // operand node ids (value = a op b)
+    float cval = 0.0f;   // CONST
+    int ipow = 0;        // POWI: literal integer exponent, |ipow| <= 16 (power rule P1)
+    uint8_t deps = 0;    // bit0 x, bit1 y, bit2 z
+};
+
+struct Program {
+    std::string equation;     // as given
+    std::vector<Node> nodes;  // topological (operands before users), CSE'd, constants folded
+    int root = -1;
+    bool uses_general_pow = false;  // some ^ is not a literal-integer power: bit parity with the
+                                    // reference is then tolerance-only
+};
+
+enum class CompileStatus { OK, PARSE, EVAL };
+
+// Symbolic execution of evaluator.cpp:53-107 / :22-48.
+CompileStatus compile(const std::string& eq, Program& out, std::string& err);
+
+// HIP source of `__device__ __forceinline__ float mc_f(float x, float y, float z)`.
+std::string emit_hip(const Program& p);
+
+// Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
+float eval_host(const Program& p, float x, float y, float z);
+
+// Power rule P1 (shared by constant folding, eval_host and -- as generated code -- the device).
+float pow_literal_int(float a, int n);
+float pow_general(float a, float b);
+
+}  // namespace mc

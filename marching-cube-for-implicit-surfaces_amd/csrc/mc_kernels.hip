@@ -1,0 +1,468 @@
+// mc_kernels.hip -- hand-written gfx950 (MI355X, wave64) kernels of the marching-cubes sweep.
+//
+// This file is compiled at run time by hiprtc, once per equation: the block between the
+// MC_F markers below is replaced by the device function the expression compiler generates
+// (mc_expr.cpp: emit_hip), so f(x,y,z) is straight-line VALU code inside the sweep and the
+// compiler hoists every sub-expression that does not depend on the walk direction out of
+// the inner loop.  It also compiles stand-alone (hipcc -c, sample f = unit sphere) so the
+// kernels can be inspected / syntax-checked without a GPU.  MUST be built with
+// -ffp-contract=off: cube codes are only bit-exact if every float op rounds once
+// (SURVEY.md section 0 item 10).
+//
+// Replaces, in the reference: the z/y/x loop of Marching::recalculate
+// (Source/marching.cpp:372-383), Marching::calculate_step (:456-595), Marching::interp
+// (:437-446), Marching::evaluate (:209-224) and Evaluator::evaluate (Source/evaluator.cpp:53).
+//
+// Data layout in HBM (all owned by the context, mc_runtime.cpp):
+//   axis   float[n1+1]        lattice coordinate c[i] (c[0]=-1, c[i+1]=c[i]+step, float adds)
+//   axs    float[3][n1+1]     scale_x*c[i], scale_y*c[i], scale_z*c[i] (marching.cpp:211)
+//   codes  u8, pitched        raw cube code per cell; row = (z-z_begin)*n1 + y, pitch % 128 == 0
+//   segcnt u32[nseg]          per SEGMENT (= 256 x-consecutive cells of one row):
+//                             triangles | active cells << 16; seg = row*nchunk + chunk
+//   segoff uint2[nseg+1]      exclusive scan of segcnt: {triangle offset, active-cell offset}
+//   verts  float[T][3][6]     {x,y,z,nx,ny,nz} per vertex, 72 B per triangle, reference order
+#ifndef MC_JIT
+#include <hip/hip_runtime.h>
+#include "../../include/mc_tables_data.h"
+#else
+#include "mc_tables_data.h"
+#endif
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+// ------------------------------------------------------------------ power rule P1
+// `^` in the reference is pow(float,float) -> libm powf (evaluator.cpp:133).  Literal
+// integer exponents become an IEEE product chain (double, one final rounding to float;
+// n == 2 is emitted as a plain float multiply, which is the same value); everything else
+// is (float)pow(double,double).  See DESIGN.md "P1" for how this relates to glibc's powf.
+template <int N>
+__device__ __forceinline__ float mc_pow_int(float a) {
+    constexpr int M = N < 0 ? -N : N;
+    const double p = (double)a;
+    double r = p;
+#pragma unroll
+    for (int i = 2; i <= M; ++i) r = r * p;
+    if (N < 0) r = 1.0 / r;
+    return (float)r;
+}
+__device__ __forceinline__ float mc_pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
+
+//@@MC_F_BEGIN  (replaced by generated code when JIT-compiled)
+__device__ __forceinline__ float mc_f(float x, float y, float z) {
+    const float t0 = z * z;
+    const float t1 = t0 - 1.0f;
+    const float t2 = y * y;
+    const float t3 = t2 + t1;
+    const float t4 = x * x;
+    return t4 + t3;  // x^2+(y^2+(z^2-1)): the reference's right-to-left reduction
+}
+//@@MC_F_END
+
+// ------------------------------------------------------------------ parameters
+struct McParams {
+    const float* axis;  // [n1+1]
+    const float* axs;   // [3][n1+1]
+    u64 pitch;          // bytes per code row
+    int n1;             // cells per axis
+    int nchunk;         // ceil(n1/256) segments per row
+    int z_begin;        // first cell layer of the slab
+    int nz;             // layers in the slab
+    int tile_h;         // classify: rows per wave tile (1..63)
+    int ntile_y;        // ceil(n1/tile_h)
+    u32 nseg;           // nz*n1*nchunk
+    u32 flags;          // MC_FLAG_*
+    float iso, step;
+    float sx, sy, sz;
+    float pad;
+    u64 cap_tris;       // capacity of the vertex buffer in triangles
+};
+
+#define MC_SEG 256          // cells per segment (4 per lane)
+#define MC_LIST_CAP 1536    // triangles staged per wave in the emit kernel (>= 5*MC_SEG)
+
+__device__ __constant__ u64 c_tri_row[256] = MC_TRI_ROW_INIT;       // marching_lookup.h:64-320, nibble-packed
+__device__ __constant__ u8 c_tri_count[256] = MC_TRI_COUNT_INIT;
+__device__ __constant__ u8 c_amb_face[256] = MC_AMB_FACE_INIT;      // :329-587 (alt row is always 255-c)
+__device__ __constant__ unsigned short c_face_corner[6] = MC_FACE_CORNER_INIT;  // :25-32
+__device__ __constant__ u8 c_edge_corner[12] = MC_EDGE_CORNER_INIT; // :10-23
+
+// corner i of a cell (marching.cpp:471-472): x offset bit, y offset bit, z offset bit
+__device__ __forceinline__ int cx_bit(int v) { return (0x66 >> v) & 1; }
+__device__ __forceinline__ int cy_bit(int v) { return (0xCC >> v) & 1; }
+__device__ __forceinline__ int cz_bit(int v) { return v >> 2; }
+
+// Marching::evaluate (marching.cpp:209-224): f(scale_x*x, scale_y*y, scale_z*z)
+__device__ __forceinline__ float mc_F(const McParams& p, float x, float y, float z) {
+    return mc_f(p.sx * x, p.sy * y, p.sz * z);
+}
+
+// acc = 2*acc + mask[lane]: one VALU op shifts a wave-mask bit into a per-lane register.
+__device__ __forceinline__ void push_bit(u32& acc, u64 m) {
+    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(acc) : "s"(m) : "vcc");
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// wavefront prefix sum (Hillis-Steele over ds_bpermute shuffles); returns the inclusive scan
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(v, d, 64);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
+// Ambiguity test of calculate_step (marching.cpp:523-549): sample f at the centre of the
+// listed face; true = take the alternative row 255-code.
+__device__ __forceinline__ bool amb_flip(const McParams& p, int face, int ix, int iy, int iz) {
+    const u32 fc = c_face_corner[face];
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = (fc >> (4 * i)) & 0xF;
+        mx += p.axis[ix + cx_bit(v)];
+        my += p.axis[iy + cy_bit(v)];
+        mz += p.axis[iz + cz_bit(v)];
+    }
+    mx *= 0.25f;  // == (float)((double)m / 4.0): an exact scaling
+    my *= 0.25f;
+    mz *= 0.25f;
+    return mc_F(p, mx, my, mz) > p.iso;
+}
+
+// =============================================================== K1: classify
+// One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer,
+// walked along y for up to 63 rows.  Every lattice sample of the two z planes is evaluated
+// once per tile row, compared once (v_cmp -> 64-bit wave mask in SGPRs), and the masks of
+// the previous row are reused, so a cell costs 2 evaluations instead of 8.  The 8-bit cube
+// codes of a lane's 4 cells are assembled into one dword by 32 carry-in adds straight from
+// the SGPR masks and stored coalesced (256 B per wave store).  Steps whose masks are all 0
+// or all 1 (the vast majority of a volume) skip the assembly.
+extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
+                                                               u32* __restrict__ segcnt) {
+    __shared__ u8 s_cnt[256];
+    __shared__ u8 s_amb[256];
+    s_cnt[threadIdx.x] = c_tri_count[threadIdx.x];
+    s_amb[threadIdx.x] = c_amb_face[threadIdx.x];
+    __syncthreads();
+
+    const McParams p = *P;
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ntiles = (long long)p.nchunk * p.ntile_y * p.nz;
+    if (tile >= ntiles) return;  // whole wave
+    const int ch = (int)(tile % p.nchunk);
+    const long long t2 = tile / p.nchunk;
+    const int ty = (int)(t2 % p.ntile_y);
+    const int lz = (int)(t2 / p.ntile_y);
+    const int iz = p.z_begin + lz;
+    const int n1 = p.n1;
+    const int x0 = ch * MC_SEG + lane * 4;
+    const int y0 = ty * p.tile_h;
+    const int ny = min(p.tile_h, n1 - y0);
+    const float iso = p.iso;
+
+    const float* __restrict__ ax = p.axs;
+    const float* __restrict__ ay = p.axs + (n1 + 1);
+    const float* __restrict__ az = p.axs + 2 * (n1 + 1);
+    // y samples of the tile's 64 sample rows live in one VGPR (lane = row); the walk reads
+    // them with v_readlane, so the inner loop issues no memory load at all.
+    const float yv = ay[min(y0 + lane, n1)];
+
+    float xs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xs[c] = ax[min(x0 + c, n1)];
+    const float xe = ax[min(ch * MC_SEG + MC_SEG, n1)];  // first sample of the next chunk
+    const float zk = az[iz], zk1 = az[iz + 1];
+
+    // sample column x = xe for the tile's 64 sample rows (lane = row): bit j of E0/E1
+    const u64 E0 = __ballot(mc_f(xe, yv, zk) > iso);
+    const u64 E1 = __ballot(mc_f(xe, yv, zk1) > iso);
+
+    u32 vmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (x0 + c < n1) vmask |= 0xFFu << (8 * c);
+
+    // masks of the current lower row: A = plane z, C = plane z+1; index 4 = sample x+4
+    u64 A[5], C[5];
+    {
+        const float yy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), 0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            A[c] = __ballot(mc_f(xs[c], yy, zk) > iso);
+            C[c] = __ballot(mc_f(xs[c], yy, zk1) > iso);
+        }
+        A[4] = (A[0] >> 1) | ((E0 & 1ull) << 63);
+        C[4] = (C[0] >> 1) | ((E1 & 1ull) << 63);
+    }
+    u64 anyA = A[0] | A[1] | A[2] | A[3] | A[4], allA = A[0] & A[1] & A[2] & A[3] & A[4];
+    u64 anyC = C[0] | C[1] | C[2] | C[3] | C[4], allC = C[0] & C[1] & C[2] & C[3] & C[4];
+
+    u32 cntreg = 0;
+    u8* __restrict__ rowp = codes + ((u64)lz * n1 + y0) * p.pitch + x0;
+
+    for (int j = 0; j < ny; ++j) {
+        const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), j + 1));
+        u64 B[5], D[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            B[c] = __ballot(mc_f(xs[c], y1, zk) > iso);
+            D[c] = __ballot(mc_f(xs[c], y1, zk1) > iso);
+        }
+        B[4] = (B[0] >> 1) | (((E0 >> (j + 1)) & 1ull) << 63);
+        D[4] = (D[0] >> 1) | (((E1 >> (j + 1)) & 1ull) << 63);
+        const u64 anyB = B[0] | B[1] | B[2] | B[3] | B[4], allB = B[0] & B[1] & B[2] & B[3] & B[4];
+        const u64 anyD = D[0] | D[1] | D[2] | D[3] | D[4], allD = D[0] & D[1] & D[2] & D[3] & D[4];
+
+        u32 dw;
+        const bool none = (anyA | anyB | anyC | anyD) == 0ull;
+        const bool full = (allA & allB & allC & allD) == ~0ull;
+        if (none) {
+            dw = 0u;
+        } else if (full) {
+            dw = 0xFFFFFFFFu;
+        } else {
+            // cube code bit i <-> corner i (marching.cpp:471-472, :497-505):
+            //   0:(x0,y0,z0)=A[c] 1:(x1,y0,z0)=A[c+1] 2:(x1,y1,z0)=B[c+1] 3:(x0,y1,z0)=B[c]
+            //   4:(x0,y0,z1)=C[c] 5:(x1,y0,z1)=C[c+1] 6:(x1,y1,z1)=D[c+1] 7:(x0,y1,z1)=D[c]
+            dw = 0u;
+#pragma unroll
+            for (int c = 3; c >= 0; --c) {
+                push_bit(dw, D[c]);
+                push_bit(dw, D[c + 1]);
+                push_bit(dw, C[c + 1]);
+                push_bit(dw, C[c]);
+                push_bit(dw, B[c]);
+                push_bit(dw, B[c + 1]);
+                push_bit(dw, A[c + 1]);
+                push_bit(dw, A[c]);
+            }
+        }
+        dw &= vmask;
+        if (x0 < n1) *(u32*)(rowp + (u64)j * p.pitch) = dw;
+
+        if (!none && !full) {  // wave-uniform: only steps that can contain surface cells
+            u32 packed = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int code = (dw >> (8 * c)) & 0xFF;
+                if (code != 0 && code != 255) {
+                    int nt = s_cnt[code];
+                    const int face = s_amb[code];
+                    if (face != 0xFF)
+                        if (amb_flip(p, face, x0 + c, y0 + j, iz)) nt = s_cnt[255 - code];
+                    packed += (u32)nt + (1u << 16);
+                }
+            }
+            packed = wave_sum(packed);
+            if (lane == j) cntreg = packed;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            A[c] = B[c];
+            C[c] = D[c];
+        }
+        anyA = anyB; allA = allB;
+        anyC = anyD; allC = allD;
+    }
+    if (lane < ny) segcnt[((u64)lz * n1 + y0 + lane) * p.nchunk + ch] = cntreg;
+}
+
+// =============================================================== K3: emit
+// Marching::interp (marching.cpp:437-446).  The fallback `x_s + 0.5*(x_e - x_s)` is evaluated
+// in double by the reference; one add of two floats rounded to double then to float equals the
+// float add (53 >= 2*24+2), so the float form below is the same value.
+__device__ __forceinline__ float mc_interp(float iso, float x_s, float x_e, float v_s, float v_e) {
+    const float v = ((iso - v_s) / (v_e - v_s)) * (x_e - x_s);
+    if (__builtin_isinf(v) || __builtin_isnan(v)) return x_s + 0.5f * (x_e - x_s);
+    return x_s + v;
+}
+
+struct McVert {
+    float x, y, z;
+};
+
+// position of triangle-vertex `slot` (0..14) of table row `row` in cell (ix,iy,iz):
+// marching.cpp:557-583 (edge interpolation, from corner v1 to corner v2 of the edge table)
+__device__ __forceinline__ McVert mc_vertex(const McParams& p, const u64* s_row, int row, int slot, int ix, int iy,
+                                            int iz) {
+    const int edge = (int)((s_row[row] >> (4 * slot)) & 0xF);
+    const int ec = c_edge_corner[edge];
+    const int v1 = ec & 0xF, v2 = ec >> 4;
+    const float xs = p.axis[ix + cx_bit(v1)], xe = p.axis[ix + cx_bit(v2)];
+    const float ys = p.axis[iy + cy_bit(v1)], ye = p.axis[iy + cy_bit(v2)];
+    const float zs = p.axis[iz + cz_bit(v1)], ze = p.axis[iz + cz_bit(v2)];
+    const float vs = mc_F(p, xs, ys, zs);
+    const float ve = mc_F(p, xe, ye, ze);
+    McVert r;
+    r.x = mc_interp(p.iso, xs, xe, vs, ve);
+    r.y = mc_interp(p.iso, ys, ye, vs, ve);
+    r.z = mc_interp(p.iso, zs, ze, vs, ve);
+    return r;
+}
+
+// One wave = one GROUP of 64 consecutive segments.  Phase 1 (per segment that has triangles):
+// read its 256 cube codes (one dword per lane), look up per-cell triangle counts, prefix-sum
+// them across the wave and expand every triangle into a 4-byte work item in LDS -- the list
+// index IS the triangle's position in the reference's emission order.  Phase 2: one lane per
+// output VERTEX: edge lookup (nibble-packed row in LDS), two corner evaluations, the three
+// interpolations, the central-difference gradient of f for the normal, 24-byte store.
+extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __restrict__ P, const u8* __restrict__ codes,
+                                                           const uint2* __restrict__ segoff, float* __restrict__ verts) {
+    __shared__ u64 s_row[256];
+    __shared__ u8 s_cnt[256];
+    __shared__ u8 s_amb[256];
+    __shared__ u32 s_list[4][MC_LIST_CAP];
+    __shared__ u32 s_seg[4][64];
+    s_row[threadIdx.x] = c_tri_row[threadIdx.x];
+    s_cnt[threadIdx.x] = c_tri_count[threadIdx.x];
+    s_amb[threadIdx.x] = c_amb_face[threadIdx.x];
+    __syncthreads();
+
+    const McParams p = *P;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const u32 group = blockIdx.x * 4u + (u32)w;
+    const u32 seg_first = group * 64u;
+    if (seg_first >= p.nseg) return;
+    const u32 seg = seg_first + (u32)lane;
+    const uint2 o0 = segoff[min(seg, p.nseg)];
+    const uint2 o1 = segoff[min(seg + 1u, p.nseg)];
+    const u32 tcount = o1.x - o0.x;
+    u64 amask = __ballot(tcount != 0u);
+    if (amask == 0ull) return;
+
+    u32* list = s_list[w];
+    u32* segrec = s_seg[w];
+    const int n1 = p.n1;
+    const float h = 0.5f * p.step;
+    const bool want_normals = (p.flags & 1u) != 0u;
+
+    u32 nlist = 0;                                              // triangles staged
+    u32 listbase = (u32)__builtin_amdgcn_readfirstlane(o0.x);   // global index of list[0]
+
+    // drains the staged triangles: one lane per vertex
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u32 nverts = 3u * nlist;
+        for (u32 v0 = 0; v0 < nverts; v0 += 64u) {
+            const u32 vid = v0 + (u32)lane;
+            if (vid < nverts) {
+                const u32 tri = vid / 3u;
+                const int k = (int)(vid - 3u * tri);
+                const u32 e = list[tri];
+                const u32 sr = segrec[e & 63u];
+                const int cellx = (int)((e >> 6) & 255u);
+                const int code = (int)((e >> 14) & 255u);
+                const int row = ((e >> 22) & 1u) ? 255 - code : code;
+                const int t = (int)((e >> 23) & 7u);
+                const int iy = (int)(sr & 2047u), iz = (int)((sr >> 11) & 2047u);
+                const int ix = (int)(sr >> 22) * MC_SEG + cellx;
+                const McVert q = mc_vertex(p, s_row, row, 3 * t + k, ix, iy, iz);
+                float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+                if (want_normals) {
+                    // n = g/|g|, g = central difference of F at the vertex, h = step/2
+                    const float gx = mc_F(p, q.x + h, q.y, q.z) - mc_F(p, q.x - h, q.y, q.z);
+                    const float gy = mc_F(p, q.x, q.y + h, q.z) - mc_F(p, q.x, q.y - h, q.z);
+                    const float gz = mc_F(p, q.x, q.y, q.z + h) - mc_F(p, q.x, q.y, q.z - h);
+                    const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+                    if (len > 0.0f && !__builtin_isinf(len)) {
+                        nx = gx / len;
+                        ny = gy / len;
+                        nz = gz / len;
+                    } else {  // degenerate gradient: the triangle's own normal cross(B-A, C-A)
+                        const McVert a = mc_vertex(p, s_row, row, 3 * t + 0, ix, iy, iz);
+                        const McVert b = mc_vertex(p, s_row, row, 3 * t + 1, ix, iy, iz);
+                        const McVert c = mc_vertex(p, s_row, row, 3 * t + 2, ix, iy, iz);
+                        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+                        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+                        const float cxn = e1y * e2z - e1z * e2y;
+                        const float cyn = e1z * e2x - e1x * e2z;
+                        const float czn = e1x * e2y - e1y * e2x;
+                        const float l = __builtin_sqrtf((cxn * cxn + cyn * cyn) + czn * czn);
+                        if (l > 0.0f && !__builtin_isinf(l)) {
+                            nx = cxn / l;
+                            ny = cyn / l;
+                            nz = czn / l;
+                        }
+                    }
+                }
+                const u64 gtri = (u64)listbase + tri;
+                if (gtri < p.cap_tris) {
+                    float2* o = (float2*)(verts + (gtri * 3ull + (u64)k) * 6ull);
+                    o[0] = make_float2(q.x, q.y);
+                    o[1] = make_float2(q.z, nx);
+                    o[2] = make_float2(ny, nz);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        listbase += nlist;
+        nlist = 0;
+    };
+
+    while (amask) {
+        const int s = __builtin_ctzll(amask);
+        amask &= amask - 1ull;
+        const u32 seg_t = (u32)__builtin_amdgcn_readlane((int)tcount, s);
+        if (nlist + seg_t > MC_LIST_CAP) flush();
+        const u32 segidx = seg_first + (u32)s;
+        const u32 rowidx = segidx / (u32)p.nchunk;
+        const int ch = (int)(segidx - rowidx * (u32)p.nchunk);
+        const int lz = (int)(rowidx / (u32)n1);
+        const int iy = (int)(rowidx - (u32)lz * (u32)n1);
+        const int iz = p.z_begin + lz;
+        if (lane == 0) segrec[s] = (u32)iy | ((u32)iz << 11) | ((u32)ch << 22);
+
+        const int x0 = ch * MC_SEG + lane * 4;
+        u32 dw = 0;
+        if (x0 < n1) dw = *(const u32*)(codes + (u64)rowidx * p.pitch + x0);
+
+        u32 meta = 0;  // per cell c: bits [4c..4c+2] triangle count, bit 4c+3 flip
+        u32 lane_t = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int code = (dw >> (8 * c)) & 0xFF;
+            if (code != 0 && code != 255 && x0 + c < n1) {
+                int nt = s_cnt[code];
+                u32 flip = 0;
+                const int face = s_amb[code];
+                if (face != 0xFF)
+                    if (amb_flip(p, face, x0 + c, iy, iz)) {
+                        nt = s_cnt[255 - code];
+                        flip = 1;
+                    }
+                meta |= ((u32)nt | (flip << 3)) << (4 * c);
+                lane_t += (u32)nt;
+            }
+        }
+        const u32 incl = wave_inclusive_scan(lane_t, lane);
+        u32 pos = nlist + (incl - lane_t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32 m = (meta >> (4 * c)) & 0xFu;
+            const u32 nt = m & 7u;
+            const u32 code = (dw >> (8 * c)) & 0xFFu;
+            const u32 base = (u32)s | ((u32)(lane * 4 + c) << 6) | (code << 14) | ((m >> 3) << 22);
+            for (u32 t = 0; t < nt; ++t) list[pos++] = base | (t << 23);
+        }
+        nlist += seg_t;
+    }
+    if (nlist) flush();
+}
+
+// =============================================================== evaluate points
+// Evaluator::evaluate(x,y,z) (evaluator.cpp:53) for a batch of points: out[i] = f(xyz[3i..3i+2]).
+extern "C" __global__ __launch_bounds__(256) void mc_eval(const float* __restrict__ xyz, float* __restrict__ out, u64 n) {
+    const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
+    if (i < n) out[i] = mc_f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+}

@@ -1,0 +1,55 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """CPU oracle (test infrastructure): oracle/mc_oracle.c through ctypes."""
+    import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def mc():
+    """The product binding (ctypes over libmc_hip.so).  Builds the library if needed."""
+    import mc_amd
+    if not mc_amd.LIB_PATH.exists():
+        mc_amd.build()
+    mc_amd.lib()
+    return mc_amd
+
+
+@pytest.fixture(scope="session")
+def ctx(mc):
+    """A GPU context; only -m gpu tests may use it (it raises without a device)."""
+    c = mc.Context(0)
+    yield c
+    c.close()
+
+
+GOLDEN = ROOT / "tests" / "golden"
+
+EQ = {
+    "eq1": "x+y",
+    "eq2": "x^2*y^2+x^2*z^2+z^2*y^2+x*y*z",
+    "eq3": "(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2",
+    "eq4": "(x^2+y^2+z^2+(1/3)^2-(5/12)^2)^2-4*((1/2)*x-(2.36/6)*(5/12))^2-4*(1/3)^2*y^2",
+    "eq5": "(x^2+y^2+z^2+(1/3)^2-(3/4)^2)^2-4*((1/2)*x-(2.36/6)*(3/4))^2-4*(1/3)^2*y^2",
+    "eq6": "(x+0.5)*(x^2+y^2+z^2-0.5^2*0.5^2*0.25)+0.5*z^2",
+    "eq7": "(x+1.5)*(x^2+y^2+z^2-((3/2)^2*(1/2)^2*0.25))+0.5*z^2",
+    "eq8": "(x^2+y^2-(1/16))^2+(y^2+z^2-(1/16))^2+(z^2+x^2-(1/16))^2-8*(x^2+y^2+z^2-(1/4))^2",
+    "sphere": "x^2+y^2+z^2-1",
+    "goursat": "(x^2)^2+(y^2)^2+(z^2)^2-(x^2+y^2+z^2)",
+    "ui_default": "(x^2+y^2-1)^2 + (x^2+z^2-1)^2 + (z^2+y^2-1)^2 - 0.5",
+}

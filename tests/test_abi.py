@@ -1,0 +1,49 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/mc_hip.h declares."""
+import ctypes
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "mc_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(mc):
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    L = ctypes.CDLL(str(mc.LIB_PATH))
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mc_hip.h but not exported"
+    assert sorted(mc.ABI_SYMBOLS) == syms
+
+
+def test_abi_version(mc):
+    assert mc.lib().mc_abi_version() == 1
+
+
+def test_no_cpu_fallback(mc):
+    """Without a GPU the library must refuse loudly, never compute on the host."""
+    if mc.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(mc.McError) as e:
+        mc.Context(0)
+    assert e.value.code == mc.MC_ERR_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_jit_source_compiles_for_gfx950(mc):
+    """hiprtc cross-compiles the specialised kernels without a GPU."""
+    assert mc.jit_precompile("x^2+y^2+z^2-1") > 10000
+    assert mc.jit_precompile("x^y+z^-3-(x/y)") > 10000
+
+
+def test_product_does_not_link_oracle(mc):
+    import subprocess
+    out = subprocess.run(["ldd", str(mc.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", str(mc.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "orc_" not in syms

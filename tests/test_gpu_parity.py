@@ -1,0 +1,258 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Bar: cube codes bit-exact; triangle soup bit-exact against the oracle in exact-power mode
+(which is far inside the north star's 1e-5) and within 1e-5 of the libm-powf (reference)
+vectors; normals within 1e-6 of the oracle's N1 definition.
+"""
+import numpy as np
+import pytest
+
+from conftest import EQ, GOLDEN
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL_POS = 1e-5   # north star: vertex positions within 1e-5 of the reference
+TOL_NRM = 1e-6
+
+
+def step_of(n):
+    return float(f32(2.0) / f32(n))
+
+
+def u32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_floats(a, b, what):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    eq = (u32(a) == u32(b)) | (np.isnan(a) & np.isnan(b))
+    assert eq.all(), f"{what}: {np.count_nonzero(~eq)} of {eq.size} floats differ, max |d| = {np.nanmax(np.abs(a - b))}"
+
+
+def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0), flags=None, z=(0, -1)):
+    flags = (mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES) if flags is None else flags
+    r = ctx.march(eq, step, iso, scale, flags, z[0], z[1])
+    o = orc.march(eq, step, iso, scale, pow_mode=orc.POW_EXACT, want=7, z_begin=z[0], z_end=z[1])
+    assert r.cells_per_axis == o.n1 and r.n_cells == o.n_cells
+    assert np.array_equal(r.codes(), o.codes), "cube codes differ"
+    assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+    v = r.vertices()
+    assert_same_floats(v[:, :, :3], o.soup, "positions")
+    assert_same_floats(r.soup(), o.soup, "soup copy")
+    if flags & mc.FLAG_NORMALS:
+        d = np.abs(v[:, :, 3:] - o.normals)
+        assert not d.size or np.nanmax(d) <= TOL_NRM, f"normals differ by {np.nanmax(d)}"
+    return r, o
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("*.npz")), ids=lambda p: p.stem)
+def test_golden(mc, ctx, path):
+    g = np.load(path)
+    r = ctx.march(str(g["equation"]), float(g["step"]), float(g["iso"]), tuple(float(s) for s in g["scale"]))
+    assert r.cells_per_axis == int(g["n1"])
+    assert np.array_equal(r.codes(), g["codes"])            # bit-exact cube indices (reference semantics)
+    assert r.n_tris == int(g["n_tris"]) and r.n_active == int(g["n_active"])
+    v = r.vertices()
+    assert np.nanmax(np.abs(v[:, :, :3] - g["soup"]), initial=0) <= TOL_POS   # vs libm-powf vectors
+    assert_same_floats(v[:, :, :3], g["soup_exact"], "positions vs exact-power vectors")
+    assert np.nanmax(np.abs(v[:, :, 3:] - g["normals"]), initial=0) <= TOL_NRM
+
+
+# ---------------------------------------------------------------- f itself
+@pytest.mark.parametrize("name", sorted(EQ))
+def test_eval_points_bit_exact(mc, orc, ctx, name):
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-1.3, 1.3, size=(4096, 3)).astype(np.float32)
+    pts[:8] = [[0, 0, 0], [1, 0, 0], [-1, 1, -1], [0.5, 0.5, 0.5], [1e-20, 1, 1], [1, 1e-30, -1], [-0.0, 0.0, 1], [1, 1, 1]]
+    got = ctx.eval_points(EQ[name], pts)
+    want = orc.evaluate_many(EQ[name], pts, pow_mode=orc.POW_EXACT)
+    assert_same_floats(got, want, "f(x,y,z)")
+
+
+@pytest.mark.parametrize("eq", ["x/y/z", "x-y-z", "-x^2", "x/y*z", "1/x", "x/(y*y-z)", "x^3", "x^-2", "x^4-y^5+z^7",
+                                "(x/3)/(y/7)", "2.36/6*x", "x^0+y^1", "-(x+ -(y)* -.021)", "xy/z^2", "x*1000000/y"])
+def test_eval_points_operators(mc, orc, ctx, eq):
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-2, 2, size=(8192, 3)).astype(np.float32)
+    pts[0] = [1, 0, 0]      # division by zero -> inf / nan must propagate like IEEE
+    pts[1] = [0, 0, 0]
+    got = ctx.eval_points(eq, pts)
+    want = orc.evaluate_many(eq, pts, pow_mode=orc.POW_EXACT)
+    assert_same_floats(got, want, eq)
+
+
+def test_eval_points_general_pow_tolerance(mc, orc, ctx):
+    """Non-literal-integer exponents: tolerance only -- parity unpinned at bit level."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0.05, 2, size=(4096, 3)).astype(np.float32)
+    for eq in ("x^y", "x^.5+z", "xy/z^-.22"):
+        got = ctx.eval_points(eq, pts)
+        want = orc.evaluate_many(eq, pts, pow_mode=orc.POW_LIBM)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-30), eq
+
+
+# ---------------------------------------------------------------- sweeps vs the oracle
+@pytest.mark.parametrize("name,n", [("sphere", 32), ("sphere", 64), ("eq1", 32), ("eq2", 32), ("eq3", 32), ("eq4", 24),
+                                    ("eq5", 24), ("eq6", 32), ("eq7", 32), ("eq8", 32), ("goursat", 32), ("eq3", 64)])
+def test_sweep_power_of_two(mc, orc, ctx, name, n):
+    check_against_oracle(mc, orc, ctx, EQ[name], step_of(n))
+
+
+@pytest.mark.parametrize("step", [0.5, 0.3, 0.25, 0.2, 0.1, 0.07, 0.0371])
+def test_sweep_odd_steps(mc, orc, ctx, step):
+    """Non power-of-two steps: the lattice is built by drifting float adds (marching.cpp:375-377)."""
+    check_against_oracle(mc, orc, ctx, EQ["sphere"], float(f32(step)), iso=0.05)
+
+
+@pytest.mark.parametrize("iso", [-0.7, -0.5, -0.4, -0.3, -0.1])
+def test_goursat_iso_sweep(mc, orc, ctx, iso):
+    r, _ = check_against_oracle(mc, orc, ctx, EQ["goursat"], step_of(32), iso=iso)
+    assert r.n_tris == {-0.7: 1984, -0.5: 13024, -0.4: 16912, -0.3: 16144, -0.1: 5728}[iso]  # SURVEY 8d cfg 5
+
+
+@pytest.mark.parametrize("scale", [(1.1, 1.1, 1.1), (0.5, 2.0, 1.0), (1.0, 1.3, 0.8)])
+def test_scaling(mc, orc, ctx, scale):  # marching.cpp:209-224
+    check_against_oracle(mc, orc, ctx, EQ["ui_default"], 0.2, scale=scale)
+    check_against_oracle(mc, orc, ctx, EQ["sphere"], step_of(24), iso=0.2, scale=scale)
+
+
+@pytest.mark.parametrize("eq,amb,flip", [("(x-0.1)*(y-0.07)-0.001", 5, 5), ("(x-0.1)*(y+0.07)-0.001", 5, 0),
+                                         ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 13, 7),
+                                         ("(x-0.1)*(y+0.07)*(z-0.13)-0.0005", 13, 8)])
+@pytest.mark.parametrize("n", [4, 20, 36])
+def test_ambiguity_branch(mc, orc, ctx, eq, amb, flip, n):
+    """marching.cpp:519-549: face-centre sample decides between row c and row 255-c."""
+    _, o = check_against_oracle(mc, orc, ctx, eq, step_of(n))
+    if n == 4:
+        assert (o.n_amb, o.n_flipped) == (amb, flip)
+    else:
+        assert o.n_amb > 0
+
+
+def test_wide_rows_multi_chunk(mc, orc, ctx):
+    """n1 > 256 and n1 % 256 != 0: several 256-cell segments per row plus a ragged tail."""
+    check_against_oracle(mc, orc, ctx, "x^2+y^2-0.5", step_of(300), z=(149, 153))      # 301 cells per row
+    check_against_oracle(mc, orc, ctx, EQ["sphere"], step_of(513), iso=0.3, z=(200, 202))  # 514 = 2*256+2
+    check_against_oracle(mc, orc, ctx, EQ["sphere"], step_of(255), z=(100, 102))       # exactly 256
+
+
+def test_dense_surface_fills_emit_staging(mc, orc, ctx):
+    """A surface that crosses nearly every cell of a row overflows the per-wave LDS list (flush path)."""
+    check_against_oracle(mc, orc, ctx, "(x*37-y*29+z*31)*(x*37-y*29+z*31)-0.3", step_of(300), z=(10, 12))
+    check_against_oracle(mc, orc, ctx, "y*y*900-0.5+x*0", step_of(300), z=(3, 5))
+
+
+def test_tile_height_does_not_matter(mc, ctx):
+    a = ctx.march(EQ["eq8"], step_of(80))
+    b = ctx.march(EQ["eq8"], step_of(80), flags=mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | mc.FLAG_TILE1)
+    ca, va = a.codes(), a.vertices()
+    assert np.array_equal(ca, b.codes()) and np.array_equal(u32(va), u32(b.vertices()))
+
+
+def test_empty_and_full_volumes(mc, orc, ctx):
+    for eq, iso in (("x^2+y^2+z^2+5", 0.0), ("x^2+y^2+z^2-50", 0.0), ("x", 10.0)):
+        r, o = check_against_oracle(mc, orc, ctx, eq, step_of(16), iso=iso)
+        assert r.n_tris == 0 and o.n_tris == 0
+
+
+def test_nan_and_inf_fields(mc, orc, ctx):
+    """NaN compares false (bit clear, marching.cpp:498); inf/nan edge values take interp's midpoint branch."""
+    check_against_oracle(mc, orc, ctx, "1/x+y", step_of(8))
+    check_against_oracle(mc, orc, ctx, "x/(y*y)+z", step_of(8))
+    check_against_oracle(mc, orc, ctx, "(x^2+y^2-.25)^.5-z", step_of(12), flags=2)  # NaN inside the cylinder
+
+
+def test_z_slabs_equal_whole(mc, ctx):
+    """Multi-GPU sharding invariant, on one GPU: concatenated Z slabs == the whole sweep, byte for byte."""
+    eq, step = EQ["eq3"], step_of(96)
+    whole = ctx.march(eq, step)
+    wc, wv = whole.codes(), whole.vertices()
+    n1 = whole.cells_per_axis
+    codes, verts = [], []
+    for rank in range(5):
+        b, e = mc.shard_layers(n1, 5, rank)
+        r = ctx.march(eq, step, z_begin=b, z_end=e)
+        codes.append(r.codes())
+        verts.append(r.vertices())
+    assert np.array_equal(np.concatenate(codes), wc)
+    assert np.array_equal(u32(np.concatenate(verts)), u32(wv))
+
+
+def test_graph_replay_equals_march(mc, ctx):
+    eq, step = EQ["goursat"], step_of(64)
+    ctx.graph_build(eq, step, iso=-0.4)
+    for iso in (-0.6, -0.45, -0.2, -0.4):
+        g = ctx.graph_replay(iso)
+        gv = g.vertices()
+        m = ctx.march(eq, step, iso, flags=mc.FLAG_NORMALS)
+        assert g.n_tris == m.n_tris and np.array_equal(u32(gv), u32(m.vertices()))
+        ctx.graph_build(eq, step, iso=-0.4)
+
+
+def test_errors(mc, ctx):
+    for eq, code in (("sin(x)", mc.MC_ERR_PARSE), ("x+", mc.MC_ERR_EVAL)):
+        with pytest.raises(mc.McError) as e:
+            ctx.march(eq, 0.25)
+        assert e.value.code == code
+    with pytest.raises(mc.McError) as e:
+        ctx.march("x+y", 0.6)          # marching.cpp:226: step outside [0.001, 0.5]
+    assert e.value.code == mc.MC_ERR_STEP
+
+
+# ---------------------------------------------------------------- larger sizes: counts + properties
+def test_sphere_256_known_answer(mc, orc, ctx):
+    """BASELINE config 2.  SURVEY.md section 4: the reference emits 617 180 triangles."""
+    r = ctx.march(EQ["sphere"], step_of(256))
+    assert (r.cells_per_axis, r.n_tris) == (257, 617180)
+    o = orc.march(EQ["sphere"], step_of(256), pow_mode=orc.POW_EXACT, want=orc.WANT_CODES | orc.WANT_SOUP)
+    assert np.array_equal(r.codes(), o.codes)
+    assert_same_floats(r.soup(), o.soup, "soup @256")
+
+
+def test_sphere_128_reference_count(mc, ctx):
+    assert ctx.march(EQ["sphere"], step_of(128), flags=0).n_tris == 154220
+
+
+def test_torus_512_properties(mc, ctx):
+    """BASELINE config 3 at full size: size-independent properties (the oracle would need ~minutes)."""
+    eq, step = EQ["eq3"], step_of(512)
+    r = ctx.march(eq, step, flags=mc.FLAG_NORMALS)
+    # 38 388 triangles @128, x4 per doubling
+    assert abs(r.n_tris / (38388 * 16) - 1) < 0.02
+    v = r.vertices()
+    p, n = v[:, :, :3], v[:, :, 3:]
+    assert np.isfinite(v).all() and p.min() >= -1 - 1e-6 and p.max() <= 1 + step + 1e-6
+    assert np.abs(np.linalg.norm(n, axis=2) - 1).max() < 1e-5
+    # every vertex lies on a lattice edge: two coordinates are lattice values
+    lat = -1 + np.arange(514) * step
+    on = np.isclose(p[..., None], lat, atol=1e-7).any(-1).sum(-1)
+    assert (on >= 2).all()
+    # orientation: cross(B-A, C-A) points toward +grad f
+    cr = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    good = np.linalg.norm(cr, axis=1) > 1e-12
+    assert ((cr[good] * n[good, 0]).sum(1) > 0).mean() > 0.999
+    # slabs == whole
+    half = r.cells_per_axis // 2
+    a = ctx.march(eq, step, flags=mc.FLAG_NORMALS, z_begin=0, z_end=half)
+    na, va = a.n_tris, a.vertices()
+    b = ctx.march(eq, step, flags=mc.FLAG_NORMALS, z_begin=half, z_end=-1)
+    assert na + b.n_tris == r.n_tris
+    assert np.array_equal(u32(np.concatenate([va, b.vertices()])), u32(v))
+
+
+def test_sphere_1024_properties(mc, ctx):
+    """The headline workload: 1025^3 cells.  Count scaling, closed-surface and on-sphere properties."""
+    r = ctx.march(EQ["sphere"], step_of(1024), flags=mc.FLAG_NORMALS)
+    assert r.cells_per_axis == 1025 and r.n_cells == 1025 ** 3
+    assert abs(r.n_tris / (617180 * 16) - 1) < 0.01           # x4 per doubling from 256
+    v = r.vertices()
+    p, n = v[:, :, :3].reshape(-1, 3), v[:, :, 3:].reshape(-1, 3)
+    rad = np.linalg.norm(p.astype(np.float64), axis=1)
+    assert abs(rad - 1).max() < 2e-6                           # linear interpolation error of x^2 at h = 1/512
+    assert np.abs((n * p).sum(1) / rad - 1).max() < 1e-4       # gradient normal is radial
+    # every edge vertex is shared by the triangles around it: positions repeat (closed surface)
+    sub = p[: 3 * 200000]
+    _, counts = np.unique(sub.view([("", np.float32)] * 3), return_counts=True)
+    assert counts.mean() > 3

@@ -1,0 +1,170 @@
+"""CPU: pin the oracle (oracle/mc_oracle.c) to everything the reference gives us.
+
+The reference has no numeric test-suite; what pins this path is
+(a) Evaluator::test() (evaluator.h:67-77), (b) the value table and tokenizer probes of
+SURVEY.md section 0/4, and (c) the counts + FNV-1a fingerprints of cube codes and
+triangle soup that SURVEY.md section 4 recorded from the unmodified reference.
+"""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import EQ, GOLDEN, ROOT
+
+f32 = np.float32
+
+
+def step_of(n):
+    return float(f32(2.0) / f32(n))
+
+
+# evaluator.h:67-77 Evaluator::test()
+REF_TOKENIZER_CASES = [("-(x+ -(y)* -.021)", 1), ("(x(y)", 0), ("(x)", 1), ("(x-)", 0), ("(-x)", 1), ("-(-x)", 1),
+                       ("", 0), ("xyz", 1), ("xy/z^-.22", 1)]
+# probes of the unmodified reference
+PROBE_TOKENIZER_CASES = [("x+", 1), ("x y", 1), ("X+Y", 1), ("1..2", 0), ("--x", 0), ("x**y", 0), ("x^^2", 0),
+                         ("1.5e1", 0), ("sin(x)", 0)]
+
+
+@pytest.mark.parametrize("eq,expect", REF_TOKENIZER_CASES + PROBE_TOKENIZER_CASES)
+def test_tokenizer_accept_reject(orc, eq, expect):
+    assert orc.tokenize(eq) == bool(expect)
+
+
+# the evaluator is right-associative and binds unary minus tighter than ^
+@pytest.mark.parametrize("eq,pt,val", [("x-y-z", (10, 3, 2), 9.0), ("x/y/z", (24, 4, 2), 12.0), ("x-y+z", (10, 3, 2), 5.0),
+                                       ("-x^2", (3, 0, 0), 9.0), ("x^2-4*y^2-4*z^2", (3, 1, 1), 21.0),
+                                       ("x/y*z", (10, 4, 2), 1.25)])
+@pytest.mark.parametrize("pm", [0, 1])
+def test_evaluation_order(orc, eq, pt, val, pm):
+    assert orc.evaluate(eq, *pt, pow_mode=pm) == val
+
+
+def test_nan_inf_propagate(orc):
+    assert np.isinf(orc.evaluate("1/x", 0.0, 0, 0))
+    assert np.isnan(orc.evaluate("x^.5", -1.0, 0, 0))
+
+
+def test_trailing_operator_is_stack_underflow(orc):
+    assert orc.tokenize("x+") and orc.evaluate("x+", 1, 2, 3) is None
+    assert orc.tokenize("x*-") and orc.evaluate("x*-", 1, 2, 3) is None
+
+
+# cells per axis = N+1, float-accumulated
+@pytest.mark.parametrize("step,n1", [(2 / 32, 33), (2 / 256, 257), (2 / 1024, 1025), (0.2, 11), (0.3, 8), (0.001, 2001)])
+def test_cells_per_axis(orc, step, n1):
+    assert orc.cells_per_axis(float(f32(step))) == n1
+
+
+def test_axis_drift(orc):  # 0.1 -> last lower corner 1.00000012
+    a = orc.axis_coords(float(f32(0.1)))
+    assert a[0] == f32(-1.0) and a[len(a) - 2] == f32(1.00000012)
+
+
+# known answers + fingerprints recorded from the unmodified reference
+#   equation, N, iso, cells, active, tris, amb, flipped, fnv(codes), fnv(soup)
+REF_FINGERPRINTS = [
+    (EQ["sphere"], 32, 0.0, 35937, 4772, 9548, 0, 0, "3a293a4d31ff065b", "4598d5da3647dd7b"),
+    (EQ["sphere"], 64, 0.0, 274625, 19244, 38492, 0, 0, "3fa68b32b77f13ab", "07a78972a906d59f"),
+    (EQ["eq1"], 32, 0.0, 35937, 2145, 4290, 0, 0, "1950087ac319be97", "3081dde6768e362b"),
+    (EQ["eq3"], 32, 0.0, 35937, 1224, 2436, 0, 0, "af8da92a3fd9a13d", "5121f2bf60815b59"),
+    (EQ["eq8"], 32, 0.0, 35937, 2824, 5632, 0, 0, "2e75c3f8432b75b1", "f20239c35f7c33c7"),
+    (EQ["eq2"], 32, 0.0, 35937, 2302, 4612, 0, 0, "7fe35be4d2b04829", "aaab3ea02c309a33"),
+    (EQ["goursat"], 32, -0.4, 35937, 8416, 16912, 0, 0, "fd486f89f66bbc5c", "61136007ac533813"),
+    ("(x-0.1)*(y-0.07)-0.001", 4, 0.0, 125, 45, 100, 5, 5, "88343fbaa746bfc6", "f0c853cc7f615c4e"),
+    ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 4, 0.0, 125, 61, 148, 13, 7, "3fe2175923bab521", "4b4bd108c366fe8f"),
+    ("(x-0.1)*(y+0.07)*(z-0.13)-0.0005", 4, 0.0, 125, 61, 148, 13, 8, "38924c48d8f5cae0", "ab531bb809938f33"),
+]
+
+
+@pytest.mark.parametrize("row", REF_FINGERPRINTS, ids=lambda r: f"{r[0][:18]}-N{r[1]}")
+@pytest.mark.parametrize("pm", [0, 1], ids=["libm", "exact"])
+def test_reference_fingerprints(orc, row, pm):
+    eq, n, iso, cells, active, tris, amb, flip, hc, hs = row
+    m = orc.march(eq, step_of(n), iso, pow_mode=pm)
+    assert (m.n_cells, m.n_active, m.n_tris, m.n_amb, m.n_flipped) == (cells, active, tris, amb, flip)
+    assert f"{m.fnv_codes:016x}" == hc
+    assert f"{m.fnv_soup:016x}" == hs
+    # the hashes are over exactly these arrays
+    assert orc.fnv1a(m.codes.tobytes()) == m.fnv_codes
+    assert orc.fnv1a(m.soup.astype("<f4").tobytes()) == m.fnv_soup
+
+
+# SURVEY.md section 4 count-only rows (no fingerprint recorded)
+@pytest.mark.parametrize("eq,n,iso,scale,active,tris,amb,flip", [
+    (EQ["sphere"], 128, 0.0, (1, 1, 1), None, 154220, None, None),
+    (EQ["eq3"], 64, 0.0, (1, 1, 1), None, 9596, None, None),
+    (EQ["ui_default"], 10, 0.0, (1.1, 1.1, 1.1), 640, 1312, 0, 0),
+    ("(x-0.1)*(y+0.07)-0.001", 4, 0.0, (1, 1, 1), 45, 100, 5, 0),
+])
+def test_reference_counts(orc, eq, n, iso, scale, active, tris, amb, flip):
+    step = 0.2 if n == 10 else step_of(n)
+    m = orc.march(eq, step, iso, scale, want=0)
+    assert m.n_tris == tris
+    if active is not None:
+        assert (m.n_active, m.n_amb, m.n_flipped) == (active, amb, flip)
+
+
+def test_goursat_iso_sweep_counts(orc):  # SURVEY.md section 8d config 5 probe @32
+    got = [orc.march(EQ["goursat"], step_of(32), iso, want=0).n_tris for iso in (-0.7, -0.5, -0.4, -0.3, -0.1)]
+    assert got == [1984, 13024, 16912, 16144, 5728]
+
+
+def test_threads_do_not_change_results(orc):
+    a = orc.march(EQ["eq8"], step_of(16), nthreads=1, want=7, pow_mode=1)
+    b = orc.march(EQ["eq8"], step_of(16), nthreads=5, want=7, pow_mode=1)
+    assert a.fnv_codes == b.fnv_codes and a.fnv_soup == b.fnv_soup
+    assert np.array_equal(a.normals.view(np.uint32), b.normals.view(np.uint32))
+
+
+def test_z_slabs_concatenate(orc):
+    whole = orc.march(EQ["sphere"], step_of(16))
+    parts = [orc.march(EQ["sphere"], step_of(16), z_begin=b, z_end=e) for b, e in ((0, 5), (5, 6), (6, 17))]
+    assert np.array_equal(np.concatenate([p.codes for p in parts]), whole.codes)
+    assert np.array_equal(np.concatenate([p.soup for p in parts]), whole.soup)
+
+
+def test_tables_against_reference_header(orc):
+    """Packed tables == the reference's marching_lookup.h compiled in place (only where it exists)."""
+    exe = ROOT / "oracle" / "_ref" / "check_tables"
+    if not Path("/root/reference/Source/marching_lookup.h").exists() and not exe.exists():
+        pytest.skip("reference not present on this machine and no prebuilt checker")
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_table_fingerprints(orc):
+    """sha256 of the tables as SURVEY.md section 7-4 recorded them from the reference."""
+    import ctypes as C
+    import hashlib
+    L = orc.lib()
+    rows = [L.orc_tri_rows()[i] for i in range(256)]
+    tri = []
+    for w in rows:
+        for k in range(16):
+            nib = (w >> (4 * k)) & 0xF
+            tri.append(-1 if nib == 0xF else nib)
+    assert hashlib.sha256(np.array(tri, np.int8).tobytes()).hexdigest() == \
+        "19bf7699e214903d72c94c296546f2e31337d637a1e4b118c3108a0f428e809b"
+    cnt = bytes(L.orc_tri_counts()[i] for i in range(256))
+    assert hashlib.sha256(cnt).hexdigest() == "fc9278a1778172f129c18226368e8413cb551e0a7ab5646152e7dfa4532a246f"
+    amb = bytes(L.orc_amb_faces()[i] for i in range(256))
+    assert hashlib.sha256(amb).hexdigest() == "049d38e7ff1728bc2742379b14bef72ff384abecff5af777d0fa2cdc76cadfc4"
+    assert sum(cnt) == 820 and sum(1 for a in amb if a != 0xFF) == 120
+
+
+def test_golden_files_match_oracle(orc):
+    """The committed fixtures are what the oracle produces today."""
+    files = sorted(GOLDEN.glob("*.npz"))
+    assert len(files) >= 10
+    for f in files:
+        g = np.load(f)
+        m = orc.march(str(g["equation"]), float(g["step"]), float(g["iso"]), tuple(float(s) for s in g["scale"]),
+                      pow_mode=orc.POW_LIBM)
+        assert np.array_equal(m.codes, g["codes"]), f.name
+        assert np.array_equal(m.soup.view(np.uint32), g["soup"].view(np.uint32)), f.name
+        assert m.fnv_codes == int(g["fnv_codes"]) and m.fnv_soup == int(g["fnv_soup"])
