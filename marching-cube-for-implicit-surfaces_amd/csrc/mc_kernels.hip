@@ -19,6 +19,9 @@
 //   codes  u8, pitched        raw cube code per cell; row = (z-z_begin)*n1 + y, pitch % 128 == 0
 //   segcnt u32[nseg]          per SEGMENT (= 256 x-consecutive cells of one row):
 //                             triangles | active cells << 16; seg = row*nchunk + chunk
+//   recs   u32[nseg][256]     per segment, its ACTIVE cells compacted in x order (only the first
+//                             `active` entries are ever written / read): cell | code<<8 | flip<<16 |
+//                             triangles<<17 | triangle prefix inside the segment<<20
 //   segoff uint2[nseg+1]      exclusive scan of segcnt: {triangle offset, active-cell offset}
 //   verts  float[T][3][6]     {x,y,z,nx,ny,nz} per vertex, 72 B per triangle, reference order
 #ifndef MC_JIT
@@ -103,20 +106,28 @@ __device__ __forceinline__ void push_bit(u32& acc, u64 m) {
     asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(acc) : "s"(m) : "vcc");
 }
 
-__device__ __forceinline__ u32 wave_sum(u32 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+// Wavefront (64-lane) inclusive prefix sum in 7 DPP adds: row_shr 1,2,3 / 4 / 8 inside the
+// 16-lane rows, then row_bcast15 / row_bcast31 across rows (gfx9 wave64 DPP controls).
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
+    u32 x = v;
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
 }
-// wavefront prefix sum (Hillis-Steele over ds_bpermute shuffles); returns the inclusive scan
-__device__ __forceinline__ u32 wave_inclusive_scan(u32 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 y = __shfl_up(v, d, 64);
-        if (lane >= d) v += y;
-    }
-    return v;
+// number of set bits of a wave mask below this lane
+__device__ __forceinline__ u32 mask_rank(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
 // Ambiguity test of calculate_step (marching.cpp:523-549): sample f at the centre of the
 // listed face; true = take the alternative row 255-code.
@@ -139,17 +150,23 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, int ix, in
 // =============================================================== K1: classify
 // One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer,
 // walked along y for up to 63 rows.  Every lattice sample of the two z planes is evaluated
-// once per tile row, compared once (v_cmp -> 64-bit wave mask in SGPRs), and the masks of
-// the previous row are reused, so a cell costs 2 evaluations instead of 8.  The 8-bit cube
-// codes of a lane's 4 cells are assembled into one dword by 32 carry-in adds straight from
-// the SGPR masks and stored coalesced (256 B per wave store).  Steps whose masks are all 0
-// or all 1 (the vast majority of a volume) skip the assembly.
+// once per tile row and the previous row's samples stay in registers, so a cell costs 2
+// evaluations instead of 8.
+//
+// Most steps of a volume are uniform (every corner of every cell on the same side of iso).
+// They are recognised on the VECTOR unit -- a min/max tree over the lane's 8 new samples and
+// two v_cmp -- because the scalar unit is shared by the CU's four SIMDs and a mask-algebra
+// test (about 50 SALU ops per step) made this kernel scalar-issue bound.  A uniform step
+// stores 0x00000000 / 0xFFFFFFFF and nothing else.
+//
+// Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair), assemble the
+// lane's four 8-bit cube codes into one dword with 32 carry-in adds, look up the triangle
+// counts, prefix-sum them across the wave (DPP) and write one compact RECORD per active cell,
+// so the emit kernel never has to look at the cube codes again.
 extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
-                                                               u32* __restrict__ segcnt) {
-    __shared__ u8 s_cnt[256];
-    __shared__ u8 s_amb[256];
-    s_cnt[threadIdx.x] = c_tri_count[threadIdx.x];
-    s_amb[threadIdx.x] = c_amb_face[threadIdx.x];
+                                                               u32* __restrict__ segcnt, u32* __restrict__ recs) {
+    __shared__ unsigned short s_lut[256];  // triangle count | ambiguity face << 8
+    s_lut[threadIdx.x] = (unsigned short)(c_tri_count[threadIdx.x] | (c_amb_face[threadIdx.x] << 8));
     __syncthreads();
 
     const McParams p = *P;
@@ -167,6 +184,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const int y0 = ty * p.tile_h;
     const int ny = min(p.tile_h, n1 - y0);
     const float iso = p.iso;
+    const float NEG_INF = -__builtin_inff();
 
     const float* __restrict__ ax = p.axs;
     const float* __restrict__ ay = p.axs + (n1 + 1);
@@ -181,54 +199,80 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const float xe = ax[min(ch * MC_SEG + MC_SEG, n1)];  // first sample of the next chunk
     const float zk = az[iz], zk1 = az[iz + 1];
 
-    // sample column x = xe for the tile's 64 sample rows (lane = row): bit j of E0/E1
+    // sample column x = xe for the tile's 64 sample rows (lane = row): bit j of E0 / E1 is the
+    // "x+4" neighbour of lane 63 in row j
     const u64 E0 = __ballot(mc_f(xe, yv, zk) > iso);
     const u64 E1 = __ballot(mc_f(xe, yv, zk1) > iso);
+    const u64 Eany = E0 | E1, Eall = E0 & E1;
 
     u32 vmask = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (x0 + c < n1) vmask |= 0xFFu << (8 * c);
 
-    // masks of the current lower row: A = plane z, C = plane z+1; index 4 = sample x+4
-    u64 A[5], C[5];
+    // samples of the current lower row: a = plane z, c = plane z+1
+    float a[4], cc[4];
+    bool prevAny, prevAll;
     {
-        const float yy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), 0));
+        const float yy = readlane_f(yv, 0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            A[c] = __ballot(mc_f(xs[c], yy, zk) > iso);
-            C[c] = __ballot(mc_f(xs[c], yy, zk1) > iso);
+            a[c] = mc_f(xs[c], yy, zk);
+            cc[c] = mc_f(xs[c], yy, zk1);
         }
-        A[4] = (A[0] >> 1) | ((E0 & 1ull) << 63);
-        C[4] = (C[0] >> 1) | ((E1 & 1ull) << 63);
+        const float mx = max3f(max3f(a[0], a[1], a[2]), max3f(a[3], cc[0], cc[1]), __builtin_fmaxf(cc[2], cc[3]));
+        const float mn = min3f(min3f(a[0], a[1], a[2]), min3f(a[3], cc[0], cc[1]), __builtin_fminf(cc[2], cc[3]));
+        const float sm = ((a[0] + a[1]) + (a[2] + a[3])) + ((cc[0] + cc[1]) + (cc[2] + cc[3]));
+        prevAny = __ballot(mx > iso) != 0ull;
+        prevAll = (__ballot(mn > iso) == ~0ull) && (__ballot(sm != sm) == 0ull);
     }
-    u64 anyA = A[0] | A[1] | A[2] | A[3] | A[4], allA = A[0] & A[1] & A[2] & A[3] & A[4];
-    u64 anyC = C[0] | C[1] | C[2] | C[3] | C[4], allC = C[0] & C[1] & C[2] & C[3] & C[4];
 
     u32 cntreg = 0;
     u8* __restrict__ rowp = codes + ((u64)lz * n1 + y0) * p.pitch + x0;
+    const u64 seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;  // segment of step 0; +nchunk per step
 
     for (int j = 0; j < ny; ++j) {
-        const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), j + 1));
-        u64 B[5], D[5];
+        const float y1 = readlane_f(yv, j + 1);
+        float b[4], d[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            B[c] = __ballot(mc_f(xs[c], y1, zk) > iso);
-            D[c] = __ballot(mc_f(xs[c], y1, zk1) > iso);
+            b[c] = mc_f(xs[c], y1, zk);
+            d[c] = mc_f(xs[c], y1, zk1);
         }
-        B[4] = (B[0] >> 1) | (((E0 >> (j + 1)) & 1ull) << 63);
-        D[4] = (D[0] >> 1) | (((E1 >> (j + 1)) & 1ull) << 63);
-        const u64 anyB = B[0] | B[1] | B[2] | B[3] | B[4], allB = B[0] & B[1] & B[2] & B[3] & B[4];
-        const u64 anyD = D[0] | D[1] | D[2] | D[3] | D[4], allD = D[0] & D[1] & D[2] & D[3] & D[4];
+        // uniformity of the new row on the vector unit.  fmax/fmin skip NaN operands, which is
+        // right for "any > iso" (NaN > iso is false, marching.cpp:498) but not for "all > iso":
+        // a NaN among samples that are otherwise all > iso shows up as a NaN sum.
+        const float mx = max3f(max3f(b[0], b[1], b[2]), max3f(b[3], d[0], d[1]), __builtin_fmaxf(d[2], d[3]));
+        const float mn = min3f(min3f(b[0], b[1], b[2]), min3f(b[3], d[0], d[1]), __builtin_fminf(d[2], d[3]));
+        const bool newAny = __ballot(mx > iso) != 0ull;
+        bool newAll = __ballot(mn > iso) == ~0ull;
+        if (newAll) {
+            const float sm = ((b[0] + b[1]) + (b[2] + b[3])) + ((d[0] + d[1]) + (d[2] + d[3]));
+            newAll = __ballot(sm != sm) == 0ull;
+        }
+        const u32 ebits_any = (u32)(Eany >> j) & 3u, ebits_all = (u32)(Eall >> j) & 3u;
+        const bool none = !prevAny && !newAny && ebits_any == 0u;
+        const bool full = prevAll && newAll && ebits_all == 3u;
 
         u32 dw;
-        const bool none = (anyA | anyB | anyC | anyD) == 0ull;
-        const bool full = (allA & allB & allC & allD) == ~0ull;
         if (none) {
             dw = 0u;
         } else if (full) {
             dw = 0xFFFFFFFFu;
         } else {
+            // wave masks of the 4 sample rows; index 4 = the lane's "x+4" sample = lane+1's sample 0
+            u64 A[5], B[5], C[5], D[5];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                A[c] = __ballot(a[c] > iso);
+                B[c] = __ballot(b[c] > iso);
+                C[c] = __ballot(cc[c] > iso);
+                D[c] = __ballot(d[c] > iso);
+            }
+            A[4] = (A[0] >> 1) | (((E0 >> j) & 1ull) << 63);
+            C[4] = (C[0] >> 1) | (((E1 >> j) & 1ull) << 63);
+            B[4] = (B[0] >> 1) | (((E0 >> (j + 1)) & 1ull) << 63);
+            D[4] = (D[0] >> 1) | (((E1 >> (j + 1)) & 1ull) << 63);
             // cube code bit i <-> corner i (marching.cpp:471-472, :497-505):
             //   0:(x0,y0,z0)=A[c] 1:(x1,y0,z0)=A[c+1] 2:(x1,y1,z0)=B[c+1] 3:(x0,y1,z0)=B[c]
             //   4:(x0,y0,z1)=C[c] 5:(x1,y0,z1)=C[c+1] 6:(x1,y1,z1)=D[c+1] 7:(x0,y1,z1)=D[c]
@@ -244,86 +288,111 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
                 push_bit(dw, A[c + 1]);
                 push_bit(dw, A[c]);
             }
-        }
-        dw &= vmask;
-        if (x0 < n1) *(u32*)(rowp + (u64)j * p.pitch) = dw;
+            dw &= vmask;
 
-        if (!none && !full) {  // wave-uniform: only steps that can contain surface cells
-            u32 packed = 0;
+            // triangle counts of the lane's cells; `meta` nibble c = count | flip<<3
+            u32 meta = 0, lane_t = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int code = (dw >> (8 * c)) & 0xFF;
                 if (code != 0 && code != 255) {
-                    int nt = s_cnt[code];
-                    const int face = s_amb[code];
+                    const u32 lut = s_lut[code];
+                    u32 nt = lut & 0xFFu, flip = 0;
+                    const int face = (int)(lut >> 8);
                     if (face != 0xFF)
-                        if (amb_flip(p, face, x0 + c, y0 + j, iz)) nt = s_cnt[255 - code];
-                    packed += (u32)nt + (1u << 16);
+                        if (amb_flip(p, face, x0 + c, y0 + j, iz)) {
+                            nt = s_lut[255 - code] & 0xFFu;
+                            flip = 1;
+                        }
+                    meta |= (nt | (flip << 3)) << (4 * c);
+                    lane_t += nt;
                 }
             }
-            packed = wave_sum(packed);
-            if (lane == j) cntreg = packed;
-        }
+            const u32 incl = wave_inclusive_scan(lane_t);
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            // rank of the lane's first active cell among the segment's active cells (x order)
+            u32 rank = 0, nact = 0;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            A[c] = B[c];
-            C[c] = D[c];
+            for (int c = 0; c < 4; ++c) {
+                const u64 m = __ballot(((meta >> (4 * c)) & 7u) != 0u);
+                rank += mask_rank(m);
+                nact += (u32)__builtin_popcountll(m);
+            }
+            u32 pre = incl - lane_t;
+            u32* __restrict__ rseg = recs + (seg0 + (u64)j * p.nchunk) * MC_SEG;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 m = (meta >> (4 * c)) & 0xFu;
+                const u32 nt = m & 7u;
+                if (nt) {
+                    rseg[rank++] = (u32)(lane * 4 + c) | (((dw >> (8 * c)) & 0xFFu) << 8) | ((m >> 3) << 16) | (nt << 17) |
+                                   (pre << 20);
+                    pre += nt;
+                }
+            }
+            if (lane == j) cntreg = total | (nact << 16);
         }
-        anyA = anyB; allA = allB;
-        anyC = anyD; allC = allD;
+        if (x0 < n1) *(u32*)(rowp + (u64)j * p.pitch) = dw;
+
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[c] = b[c];
+            cc[c] = d[c];
+        }
+        prevAny = newAny;
+        prevAll = newAll;
     }
-    if (lane < ny) segcnt[((u64)lz * n1 + y0 + lane) * p.nchunk + ch] = cntreg;
+    if (lane < ny) segcnt[seg0 + (u64)lane * p.nchunk] = cntreg;
 }
 
 // =============================================================== K3: emit
-// Marching::interp (marching.cpp:437-446).  The fallback `x_s + 0.5*(x_e - x_s)` is evaluated
-// in double by the reference; one add of two floats rounded to double then to float equals the
-// float add (53 >= 2*24+2), so the float form below is the same value.
-__device__ __forceinline__ float mc_interp(float iso, float x_s, float x_e, float v_s, float v_e) {
-    const float v = ((iso - v_s) / (v_e - v_s)) * (x_e - x_s);
-    if (__builtin_isinf(v) || __builtin_isnan(v)) return x_s + 0.5f * (x_e - x_s);
-    return x_s + v;
-}
-
 struct McVert {
     float x, y, z;
 };
 
 // position of triangle-vertex `slot` (0..14) of table row `row` in cell (ix,iy,iz):
-// marching.cpp:557-583 (edge interpolation, from corner v1 to corner v2 of the edge table)
-__device__ __forceinline__ McVert mc_vertex(const McParams& p, const u64* s_row, int row, int slot, int ix, int iy,
-                                            int iz) {
+// marching.cpp:557-583 (edge interpolation from corner v1 to corner v2 of the edge table) with
+// Marching::interp (:437-446) applied to x, y and z.  The reference evaluates the quotient
+// (iso - v_s)/(v_e - v_s) once per axis with identical operands; it is computed once here.
+// The fallback `x_s + 0.5*(x_e - x_s)` is evaluated in double by the reference; one add of two
+// floats rounded to double and then to float equals the float add (53 >= 2*24+2).
+__device__ __forceinline__ McVert mc_vertex(const McParams& p, const u64* s_row, const u8* s_edge, int row, int slot,
+                                            int ix, int iy, int iz) {
     const int edge = (int)((s_row[row] >> (4 * slot)) & 0xF);
-    const int ec = c_edge_corner[edge];
+    const int ec = s_edge[edge];
     const int v1 = ec & 0xF, v2 = ec >> 4;
     const float xs = p.axis[ix + cx_bit(v1)], xe = p.axis[ix + cx_bit(v2)];
     const float ys = p.axis[iy + cy_bit(v1)], ye = p.axis[iy + cy_bit(v2)];
     const float zs = p.axis[iz + cz_bit(v1)], ze = p.axis[iz + cz_bit(v2)];
     const float vs = mc_F(p, xs, ys, zs);
     const float ve = mc_F(p, xe, ye, ze);
+    const float t = (p.iso - vs) / (ve - vs);
+    const float dx = xe - xs, dy = ye - ys, dz = ze - zs;
+    const float vx = t * dx, vy = t * dy, vz = t * dz;
     McVert r;
-    r.x = mc_interp(p.iso, xs, xe, vs, ve);
-    r.y = mc_interp(p.iso, ys, ye, vs, ve);
-    r.z = mc_interp(p.iso, zs, ze, vs, ve);
+    r.x = (__builtin_isinf(vx) || __builtin_isnan(vx)) ? xs + 0.5f * dx : xs + vx;
+    r.y = (__builtin_isinf(vy) || __builtin_isnan(vy)) ? ys + 0.5f * dy : ys + vy;
+    r.z = (__builtin_isinf(vz) || __builtin_isnan(vz)) ? zs + 0.5f * dz : zs + vz;
     return r;
 }
 
-// One wave = one GROUP of 64 consecutive segments.  Phase 1 (per segment that has triangles):
-// read its 256 cube codes (one dword per lane), look up per-cell triangle counts, prefix-sum
-// them across the wave and expand every triangle into a 4-byte work item in LDS -- the list
-// index IS the triangle's position in the reference's emission order.  Phase 2: one lane per
-// output VERTEX: edge lookup (nibble-packed row in LDS), two corner evaluations, the three
-// interpolations, the central-difference gradient of f for the normal, 24-byte store.
-extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __restrict__ P, const u8* __restrict__ codes,
+// One wave = one GROUP of 64 consecutive segments.  Phase 1, one lane per RECORD (= active
+// cell, written by mc_classify): find the owning segment by binary search over the group's
+// active-cell offsets (LDS), read the record, and expand its triangles into 4-byte work items
+// in LDS -- the list index is the triangle's position in the reference's emission order.
+// Phase 2, one lane per output VERTEX: edge lookup (nibble-packed table row in LDS), two corner
+// evaluations, the interpolation, the central-difference gradient of f for the normal, 24-byte
+// store.
+extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                            const uint2* __restrict__ segoff, float* __restrict__ verts) {
     __shared__ u64 s_row[256];
-    __shared__ u8 s_cnt[256];
-    __shared__ u8 s_amb[256];
+    __shared__ u8 s_edge[16];
     __shared__ u32 s_list[4][MC_LIST_CAP];
     __shared__ u32 s_seg[4][64];
+    __shared__ u32 s_act[4][66];
+    __shared__ u32 s_tri[4][64];
     s_row[threadIdx.x] = c_tri_row[threadIdx.x];
-    s_cnt[threadIdx.x] = c_tri_count[threadIdx.x];
-    s_amb[threadIdx.x] = c_amb_face[threadIdx.x];
+    if (threadIdx.x < 12) s_edge[threadIdx.x] = c_edge_corner[threadIdx.x];
     __syncthreads();
 
     const McParams p = *P;
@@ -335,18 +404,31 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
     const u32 seg = seg_first + (u32)lane;
     const uint2 o0 = segoff[min(seg, p.nseg)];
     const uint2 o1 = segoff[min(seg + 1u, p.nseg)];
-    const u32 tcount = o1.x - o0.x;
-    u64 amask = __ballot(tcount != 0u);
-    if (amask == 0ull) return;
+    const u32 act_base = (u32)__builtin_amdgcn_readfirstlane((int)o0.y);
+    const u32 nrec = (u32)__builtin_amdgcn_readlane((int)o1.y, 63) - act_base;  // records of the group
+    if (nrec == 0u) return;
 
     u32* list = s_list[w];
     u32* segrec = s_seg[w];
+    u32* actoff = s_act[w];
+    u32* trioff = s_tri[w];
     const int n1 = p.n1;
+    {
+        const u32 sg = min(seg, p.nseg - 1u);
+        const u32 rowidx = sg / (u32)p.nchunk;
+        const u32 ch = sg - rowidx * (u32)p.nchunk;
+        const u32 lz = rowidx / (u32)n1;
+        const u32 iy = rowidx - lz * (u32)n1;
+        segrec[lane] = iy | ((u32)(p.z_begin + (int)lz) << 11) | (ch << 22);
+        actoff[lane] = o0.y - act_base;
+        trioff[lane] = o0.x;
+        if (lane == 63) actoff[64] = o1.y - act_base;
+    }
     const float h = 0.5f * p.step;
     const bool want_normals = (p.flags & 1u) != 0u;
 
-    u32 nlist = 0;                                              // triangles staged
-    u32 listbase = (u32)__builtin_amdgcn_readfirstlane(o0.x);   // global index of list[0]
+    u32 nlist = 0;                                             // triangles staged
+    u32 listbase = (u32)__builtin_amdgcn_readfirstlane((int)o0.x);  // global index of list[0]
 
     // drains the staged triangles: one lane per vertex
     auto flush = [&]() {
@@ -366,7 +448,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
                 const int t = (int)((e >> 23) & 7u);
                 const int iy = (int)(sr & 2047u), iz = (int)((sr >> 11) & 2047u);
                 const int ix = (int)(sr >> 22) * MC_SEG + cellx;
-                const McVert q = mc_vertex(p, s_row, row, 3 * t + k, ix, iy, iz);
+                const McVert q = mc_vertex(p, s_row, s_edge, row, 3 * t + k, ix, iy, iz);
                 float nx = 0.0f, ny = 0.0f, nz = 0.0f;
                 if (want_normals) {
                     // n = g/|g|, g = central difference of F at the vertex, h = step/2
@@ -379,9 +461,9 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
                         ny = gy / len;
                         nz = gz / len;
                     } else {  // degenerate gradient: the triangle's own normal cross(B-A, C-A)
-                        const McVert a = mc_vertex(p, s_row, row, 3 * t + 0, ix, iy, iz);
-                        const McVert b = mc_vertex(p, s_row, row, 3 * t + 1, ix, iy, iz);
-                        const McVert c = mc_vertex(p, s_row, row, 3 * t + 2, ix, iy, iz);
+                        const McVert a = mc_vertex(p, s_row, s_edge, row, 3 * t + 0, ix, iy, iz);
+                        const McVert b = mc_vertex(p, s_row, s_edge, row, 3 * t + 1, ix, iy, iz);
+                        const McVert c = mc_vertex(p, s_row, s_edge, row, 3 * t + 2, ix, iy, iz);
                         const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
                         const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
                         const float cxn = e1y * e2z - e1z * e2y;
@@ -410,52 +492,33 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
         nlist = 0;
     };
 
-    while (amask) {
-        const int s = __builtin_ctzll(amask);
-        amask &= amask - 1ull;
-        const u32 seg_t = (u32)__builtin_amdgcn_readlane((int)tcount, s);
-        if (nlist + seg_t > MC_LIST_CAP) flush();
-        const u32 segidx = seg_first + (u32)s;
-        const u32 rowidx = segidx / (u32)p.nchunk;
-        const int ch = (int)(segidx - rowidx * (u32)p.nchunk);
-        const int lz = (int)(rowidx / (u32)n1);
-        const int iy = (int)(rowidx - (u32)lz * (u32)n1);
-        const int iz = p.z_begin + lz;
-        if (lane == 0) segrec[s] = (u32)iy | ((u32)iz << 11) | ((u32)ch << 22);
-
-        const int x0 = ch * MC_SEG + lane * 4;
-        u32 dw = 0;
-        if (x0 < n1) dw = *(const u32*)(codes + (u64)rowidx * p.pitch + x0);
-
-        u32 meta = 0;  // per cell c: bits [4c..4c+2] triangle count, bit 4c+3 flip
-        u32 lane_t = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 r0 = 0; r0 < nrec; r0 += 64u) {
+        const u32 r = r0 + (u32)lane;
+        const bool valid = r < nrec;
+        // owning segment: the largest s with actoff[s] <= r (empty segments repeat the value)
+        u32 lo = 0, hi = 64;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int code = (dw >> (8 * c)) & 0xFF;
-            if (code != 0 && code != 255 && x0 + c < n1) {
-                int nt = s_cnt[code];
-                u32 flip = 0;
-                const int face = s_amb[code];
-                if (face != 0xFF)
-                    if (amb_flip(p, face, x0 + c, iy, iz)) {
-                        nt = s_cnt[255 - code];
-                        flip = 1;
-                    }
-                meta |= ((u32)nt | (flip << 3)) << (4 * c);
-                lane_t += (u32)nt;
-            }
+        for (int it = 0; it < 6; ++it) {
+            const u32 mid = (lo + hi) >> 1;
+            if (actoff[mid] <= r) lo = mid; else hi = mid;
         }
-        const u32 incl = wave_inclusive_scan(lane_t, lane);
-        u32 pos = nlist + (incl - lane_t);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32 m = (meta >> (4 * c)) & 0xFu;
-            const u32 nt = m & 7u;
-            const u32 code = (dw >> (8 * c)) & 0xFFu;
-            const u32 base = (u32)s | ((u32)(lane * 4 + c) << 6) | (code << 14) | ((m >> 3) << 22);
-            for (u32 t = 0; t < nt; ++t) list[pos++] = base | (t << 23);
+        u32 rec = 0, gtri0 = 0;
+        if (valid) {
+            rec = recs[((u64)seg_first + lo) * MC_SEG + (r - actoff[lo])];
+            gtri0 = trioff[lo] + (rec >> 20);
         }
-        nlist += seg_t;
+        const u32 nt = (rec >> 17) & 7u;
+        // the chunk's triangles are one contiguous range of the global order
+        const int lv = (int)min(63u, nrec - 1u - r0);
+        const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
+        const u32 chunk_t = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), lv) - first;
+        if (nlist + chunk_t > MC_LIST_CAP) flush();
+        const u32 base = (gtri0 - listbase) & 0xFFFFFFFFu;
+        const u32 item = lo | ((rec & 0xFFu) << 6) | (((rec >> 8) & 0xFFu) << 14) | (((rec >> 16) & 1u) << 22);
+        for (u32 t = 0; t < nt; ++t) list[base + t] = item | (t << 23);
+        nlist += chunk_t;
     }
     if (nlist) flush();
 }
