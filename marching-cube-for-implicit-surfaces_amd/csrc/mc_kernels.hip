@@ -83,7 +83,7 @@ struct McParams {
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
-#define MC_LIST_CAP 1536    // triangles staged per wave in the emit kernel (>= 5*MC_SEG)
+#define MC_LIST_CAP 768     // triangles staged per wave in the emit kernel (>= 64 records * 5)
 
 __device__ __constant__ u64 c_tri_row[256] = MC_TRI_ROW_INIT;       // marching_lookup.h:64-320, nibble-packed
 __device__ __constant__ u8 c_tri_count[256] = MC_TRI_COUNT_INIT;
@@ -119,6 +119,18 @@ __device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
     return x;
 }
+// same ladder with max instead of add (values are unsigned; 0 is the identity)
+__device__ __forceinline__ u32 wave_inclusive_max(u32 v) {
+    u32 x = v;
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ u32 mask_rank(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
@@ -151,27 +163,108 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, int ix, in
 // One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer,
 // walked along y for up to 63 rows.  Every lattice sample of the two z planes is evaluated
 // once per tile row and the previous row's samples stay in registers, so a cell costs 2
-// evaluations instead of 8.
+// evaluations instead of 8.  The kernel is bound by vector-instruction issue (a wave64 VALU
+// op occupies its SIMD for ~4 cycles; measured, profiles/), so the design minimises VALU ops:
 //
-// Most steps of a volume are uniform (every corner of every cell on the same side of iso).
-// They are recognised on the VECTOR unit -- a min/max tree over the lane's 8 new samples and
-// two v_cmp -- because the scalar unit is shared by the CU's four SIMDs and a mask-algebra
-// test (about 50 SALU ops per step) made this kernel scalar-issue bound.  A uniform step
-// stores 0x00000000 / 0xFFFFFFFF and nothing else.
-//
-// Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair), assemble the
-// lane's four 8-bit cube codes into one dword with 32 carry-in adds, look up the triangle
-// counts, prefix-sum them across the wave (DPP) and write one compact RECORD per active cell,
-// so the emit kernel never has to look at the cube codes again.
+//  * Uniform steps (every corner of all 256 cells on one side of iso -- most of a volume) are
+//    recognised with a min/max tree over the lane's 8 new samples and two v_cmp, and store
+//    0x00000000 / 0xFFFFFFFF.  ~20 VALU ops per 256 cells.  (A mask-algebra version of this
+//    test cost ~50 scalar ops per step and made the kernel scalar-issue bound: the scalar
+//    unit is shared by the CU's four SIMDs.)
+//  * Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair; the lower
+//    row's masks are carried over when the previous step was mixed too) and assemble the
+//    lane's four 8-bit cube codes into one dword with 32 carry-in adds.  Lanes whose dword is
+//    not 0 / ~0 append it to a small per-wave LDS list.
+//  * The expensive part -- triangle-count lookup, ambiguity test, per-segment prefix sums and
+//    the compact per-cell RECORDS the emit kernel consumes -- runs lane-parallel over that
+//    list once per tile (a tile has ~35 mixed dwords on a smooth surface) instead of
+//    wave-wide in each of its ~20 mixed steps.
+#define MC_ENT_CAP 256  // mixed dwords staged per wave before the record pass runs
+
+struct McTileCtx {
+    int ch, y0, iz, lane;
+    u64 seg0;  // segment index of tile row 0; + nchunk per row
+};
+
+// lane-parallel pass over the staged mixed dwords (entries sorted by (row, lane))
+__device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCtx& t, const unsigned short* s_lut,
+                                               const u32* ent_dw, const unsigned short* ent_pos, u32* seg_cnt, u32 nent,
+                                               u32* __restrict__ recs, int& carry_j, u32& carry_val) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 e0 = 0; e0 < nent; e0 += 64u) {
+        const u32 e = e0 + (u32)t.lane;
+        const bool valid = e < nent;
+        const u32 dw = valid ? ent_dw[e] : 0u;
+        const u32 pos = valid ? ent_pos[e] : 0xFFFFu;
+        const int j = (int)(pos >> 6), ln = (int)(pos & 63u);
+        // per cell: triangle count and ambiguity flip; meta nibble c = count | flip<<3
+        u32 meta = 0, packed = 0;  // packed = triangles | active cells << 16 of this entry
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int code = (dw >> (8 * c)) & 0xFF;
+            if (code != 0 && code != 255) {
+                const u32 lut = s_lut[code];
+                u32 nt = lut & 0xFFu, flip = 0;
+                const int face = (int)(lut >> 8);
+                if (face != 0xFF)
+                    if (amb_flip(p, face, t.ch * MC_SEG + ln * 4 + c, t.y0 + j, t.iz)) {
+                        nt = s_lut[255 - code] & 0xFFu;
+                        flip = 1;
+                    }
+                meta |= (nt | (flip << 3)) << (4 * c);
+                packed += nt + (1u << 16);
+            }
+        }
+        // prefix inside each segment (= tile row j): wave scan minus the scan value at the
+        // segment's first entry; both halves of `packed` are non-decreasing, so a max-scan of
+        // "exclusive value at segment heads" propagates the base to the followers.
+        const u32 incl = wave_inclusive_scan(packed);
+        const u32 excl = incl - packed;
+        const int jprev = __builtin_amdgcn_update_dpp(-1, j, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const bool head = valid && (t.lane == 0 || jprev != j);
+        const u32 base = wave_inclusive_max(head ? excl : 0u);
+        const int j0 = __builtin_amdgcn_readfirstlane(j);
+        u32 pre = excl - base;
+        if (j == j0 && j0 == carry_j) pre += carry_val;  // segment continues from the previous 64 entries
+        if (valid) {
+            // segment totals: order-independent LDS adds; slot j is read by lane j at tile end
+            if (packed) __hip_atomic_fetch_add(&seg_cnt[j], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            u32* __restrict__ rseg = recs + (t.seg0 + (u64)j * p.nchunk) * MC_SEG;
+            u32 rank = pre >> 16, tpre = pre & 0xFFFFu;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 m = (meta >> (4 * c)) & 0xFu;
+                const u32 nt = m & 7u;
+                if (nt) {
+                    rseg[rank++] = (u32)(ln * 4 + c) | (((dw >> (8 * c)) & 0xFFu) << 8) | ((m >> 3) << 16) | (nt << 17) |
+                                   (tpre << 20);
+                    tpre += nt;
+                }
+            }
+        }
+        // carry for a segment that spans two 64-entry chunks
+        const int lv = (int)min(63u, nent - 1u - e0);
+        carry_j = __builtin_amdgcn_readlane(j, lv);
+        carry_val = (u32)__builtin_amdgcn_readlane((int)(pre + packed), lv);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
                                                                u32* __restrict__ segcnt, u32* __restrict__ recs) {
     __shared__ unsigned short s_lut[256];  // triangle count | ambiguity face << 8
+    __shared__ u32 s_ent_dw[4][MC_ENT_CAP];
+    __shared__ unsigned short s_ent_pos[4][MC_ENT_CAP];
+    __shared__ u32 s_segcnt[4][64];
     s_lut[threadIdx.x] = (unsigned short)(c_tri_count[threadIdx.x] | (c_amb_face[threadIdx.x] << 8));
     __syncthreads();
 
     const McParams p = *P;
     const int lane = threadIdx.x & 63;
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * 4 + w;
     const long long ntiles = (long long)p.nchunk * p.ntile_y * p.nz;
     if (tile >= ntiles) return;  // whole wave
     const int ch = (int)(tile % p.nchunk);
@@ -184,7 +277,11 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const int y0 = ty * p.tile_h;
     const int ny = min(p.tile_h, n1 - y0);
     const float iso = p.iso;
-    const float NEG_INF = -__builtin_inff();
+
+    u32* ent_dw = s_ent_dw[w];
+    unsigned short* ent_pos = s_ent_pos[w];
+    u32* seg_cnt = s_segcnt[w];
+    seg_cnt[lane] = 0u;
 
     const float* __restrict__ ax = p.axs;
     const float* __restrict__ ay = p.axs + (n1 + 1);
@@ -210,7 +307,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     for (int c = 0; c < 4; ++c)
         if (x0 + c < n1) vmask |= 0xFFu << (8 * c);
 
-    // samples of the current lower row: a = plane z, c = plane z+1
+    // samples of the current lower row: a = plane z, cc = plane z+1
     float a[4], cc[4];
     bool prevAny, prevAll;
     {
@@ -227,9 +324,18 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         prevAll = (__ballot(mn > iso) == ~0ull) && (__ballot(sm != sm) == 0ull);
     }
 
-    u32 cntreg = 0;
+    McTileCtx tc;
+    tc.ch = ch;
+    tc.y0 = y0;
+    tc.iz = iz;
+    tc.lane = lane;
+    tc.seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;
+    u32 nent = 0;
+    int carry_j = -1;
+    u32 carry_val = 0;
+    u64 A[5], C[5];  // lower-row masks, valid while haveAC
+    bool haveAC = false;
     u8* __restrict__ rowp = codes + ((u64)lz * n1 + y0) * p.pitch + x0;
-    const u64 seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;  // segment of step 0; +nchunk per step
 
     for (int j = 0; j < ny; ++j) {
         const float y1 = readlane_f(yv, j + 1);
@@ -257,20 +363,27 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         u32 dw;
         if (none) {
             dw = 0u;
+            haveAC = false;
         } else if (full) {
-            dw = 0xFFFFFFFFu;
+            dw = 0xFFFFFFFFu & vmask;
+            haveAC = false;
         } else {
             // wave masks of the 4 sample rows; index 4 = the lane's "x+4" sample = lane+1's sample 0
-            u64 A[5], B[5], C[5], D[5];
+            u64 B[5], D[5];
+            if (!haveAC) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    A[c] = __ballot(a[c] > iso);
+                    C[c] = __ballot(cc[c] > iso);
+                }
+                A[4] = (A[0] >> 1) | (((E0 >> j) & 1ull) << 63);
+                C[4] = (C[0] >> 1) | (((E1 >> j) & 1ull) << 63);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                A[c] = __ballot(a[c] > iso);
                 B[c] = __ballot(b[c] > iso);
-                C[c] = __ballot(cc[c] > iso);
                 D[c] = __ballot(d[c] > iso);
             }
-            A[4] = (A[0] >> 1) | (((E0 >> j) & 1ull) << 63);
-            C[4] = (C[0] >> 1) | (((E1 >> j) & 1ull) << 63);
             B[4] = (B[0] >> 1) | (((E0 >> (j + 1)) & 1ull) << 63);
             D[4] = (D[0] >> 1) | (((E1 >> (j + 1)) & 1ull) << 63);
             // cube code bit i <-> corner i (marching.cpp:471-472, :497-505):
@@ -289,48 +402,26 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
                 push_bit(dw, A[c]);
             }
             dw &= vmask;
-
-            // triangle counts of the lane's cells; `meta` nibble c = count | flip<<3
-            u32 meta = 0, lane_t = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int code = (dw >> (8 * c)) & 0xFF;
-                if (code != 0 && code != 255) {
-                    const u32 lut = s_lut[code];
-                    u32 nt = lut & 0xFFu, flip = 0;
-                    const int face = (int)(lut >> 8);
-                    if (face != 0xFF)
-                        if (amb_flip(p, face, x0 + c, y0 + j, iz)) {
-                            nt = s_lut[255 - code] & 0xFFu;
-                            flip = 1;
-                        }
-                    meta |= (nt | (flip << 3)) << (4 * c);
-                    lane_t += nt;
+            for (int c = 0; c < 5; ++c) {
+                A[c] = B[c];
+                C[c] = D[c];
+            }
+            haveAC = true;
+            // stage the lanes that may hold surface cells (dword neither all-0 nor all-1 bytes)
+            const u64 m = __ballot(dw != 0u && dw != 0xFFFFFFFFu);
+            if (m) {
+                if (nent + (u32)__builtin_popcountll(m) > MC_ENT_CAP) {
+                    mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
+                    nent = 0;
                 }
-            }
-            const u32 incl = wave_inclusive_scan(lane_t);
-            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-            // rank of the lane's first active cell among the segment's active cells (x order)
-            u32 rank = 0, nact = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u64 m = __ballot(((meta >> (4 * c)) & 7u) != 0u);
-                rank += mask_rank(m);
-                nact += (u32)__builtin_popcountll(m);
-            }
-            u32 pre = incl - lane_t;
-            u32* __restrict__ rseg = recs + (seg0 + (u64)j * p.nchunk) * MC_SEG;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u32 m = (meta >> (4 * c)) & 0xFu;
-                const u32 nt = m & 7u;
-                if (nt) {
-                    rseg[rank++] = (u32)(lane * 4 + c) | (((dw >> (8 * c)) & 0xFFu) << 8) | ((m >> 3) << 16) | (nt << 17) |
-                                   (pre << 20);
-                    pre += nt;
+                if (dw != 0u && dw != 0xFFFFFFFFu) {
+                    const u32 idx = nent + mask_rank(m);
+                    ent_dw[idx] = dw;
+                    ent_pos[idx] = (unsigned short)((j << 6) | lane);
                 }
+                nent += (u32)__builtin_popcountll(m);
             }
-            if (lane == j) cntreg = total | (nact << 16);
         }
         if (x0 < n1) *(u32*)(rowp + (u64)j * p.pitch) = dw;
 
@@ -342,7 +433,10 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         prevAny = newAny;
         prevAll = newAll;
     }
-    if (lane < ny) segcnt[seg0 + (u64)lane * p.nchunk] = cntreg;
+    if (nent) mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ny) segcnt[tc.seg0 + (u64)lane * p.nchunk] = seg_cnt[lane];
 }
 
 // =============================================================== K3: emit
