@@ -171,9 +171,8 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, int ix, in
 //    0x00000000 / 0xFFFFFFFF.  ~20 VALU ops per 256 cells.  (A mask-algebra version of this
 //    test cost ~50 scalar ops per step and made the kernel scalar-issue bound: the scalar
 //    unit is shared by the CU's four SIMDs.)
-//  * Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair; the lower
-//    row's masks are carried over when the previous step was mixed too) and assemble the
-//    lane's four 8-bit cube codes into one dword with 32 carry-in adds.  Lanes whose dword is
+//  * Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair) and assemble
+//    the lane's four 8-bit cube codes into one dword with 32 carry-in adds.  Lanes whose dword is
 //    not 0 / ~0 append it to a small per-wave LDS list.
 //  * The expensive part -- triangle-count lookup, ambiguity test, per-segment prefix sums and
 //    the compact per-cell RECORDS the emit kernel consumes -- runs lane-parallel over that
@@ -263,7 +262,9 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
 
     const McParams p = *P;
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    // the wave index is wave-uniform, but the compiler only knows that if told: without the
+    // readfirstlane every tile coordinate (and the whole walk's scalar algebra) lands in VGPRs
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long tile = (long long)blockIdx.x * 4 + w;
     const long long ntiles = (long long)p.nchunk * p.ntile_y * p.nz;
     if (tile >= ntiles) return;  // whole wave
@@ -300,29 +301,11 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     // "x+4" neighbour of lane 63 in row j
     const u64 E0 = __ballot(mc_f(xe, yv, zk) > iso);
     const u64 E1 = __ballot(mc_f(xe, yv, zk1) > iso);
-    const u64 Eany = E0 | E1, Eall = E0 & E1;
 
     u32 vmask = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (x0 + c < n1) vmask |= 0xFFu << (8 * c);
-
-    // samples of the current lower row: a = plane z, cc = plane z+1
-    float a[4], cc[4];
-    bool prevAny, prevAll;
-    {
-        const float yy = readlane_f(yv, 0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            a[c] = mc_f(xs[c], yy, zk);
-            cc[c] = mc_f(xs[c], yy, zk1);
-        }
-        const float mx = max3f(max3f(a[0], a[1], a[2]), max3f(a[3], cc[0], cc[1]), __builtin_fmaxf(cc[2], cc[3]));
-        const float mn = min3f(min3f(a[0], a[1], a[2]), min3f(a[3], cc[0], cc[1]), __builtin_fminf(cc[2], cc[3]));
-        const float sm = ((a[0] + a[1]) + (a[2] + a[3])) + ((cc[0] + cc[1]) + (cc[2] + cc[3]));
-        prevAny = __ballot(mx > iso) != 0ull;
-        prevAll = (__ballot(mn > iso) == ~0ull) && (__ballot(sm != sm) == 0ull);
-    }
 
     McTileCtx tc;
     tc.ch = ch;
@@ -333,106 +316,117 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     u32 nent = 0;
     int carry_j = -1;
     u32 carry_val = 0;
-    u64 A[5], C[5];  // lower-row masks, valid while haveAC
-    bool haveAC = false;
-    u8* __restrict__ rowp = codes + ((u64)lz * n1 + y0) * p.pitch + x0;
 
-    for (int j = 0; j < ny; ++j) {
-        const float y1 = readlane_f(yv, j + 1);
-        float b[4], d[4];
+    // Two sample-row register sets (plane z / plane z+1 each) and two wave-mask sets ping-pong
+    // between "lower row" and "upper row" so the walk never copies registers.
+    float r0a[4], r0c[4], r1a[4], r1c[4];
+    u64 gtPrev, gePrev;    // ballots of the lower row: max-of-lane > iso, min-of-lane > iso
+    bool nanPrev;          // lower row has a NaN among samples that otherwise all exceed iso
+    // row base of the code plane as a wave-uniform pointer + 32-bit lane offset (saddr store)
+    u8* __restrict__ rowbase = codes + ((u64)lz * n1 + y0) * p.pitch;
+    const u32 xoff = (u32)x0;
+
+    auto eval_row = [&](float y, float (&ra)[4], float (&rc)[4], u64& gt, u64& ge, bool& hasnan) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            b[c] = mc_f(xs[c], y1, zk);
-            d[c] = mc_f(xs[c], y1, zk1);
+            ra[c] = mc_f(xs[c], y, zk);
+            rc[c] = mc_f(xs[c], y, zk1);
         }
-        // uniformity of the new row on the vector unit.  fmax/fmin skip NaN operands, which is
-        // right for "any > iso" (NaN > iso is false, marching.cpp:498) but not for "all > iso":
-        // a NaN among samples that are otherwise all > iso shows up as a NaN sum.
-        const float mx = max3f(max3f(b[0], b[1], b[2]), max3f(b[3], d[0], d[1]), __builtin_fmaxf(d[2], d[3]));
-        const float mn = min3f(min3f(b[0], b[1], b[2]), min3f(b[3], d[0], d[1]), __builtin_fminf(d[2], d[3]));
-        const bool newAny = __ballot(mx > iso) != 0ull;
-        bool newAll = __ballot(mn > iso) == ~0ull;
-        if (newAll) {
-            const float sm = ((b[0] + b[1]) + (b[2] + b[3])) + ((d[0] + d[1]) + (d[2] + d[3]));
-            newAll = __ballot(sm != sm) == 0ull;
+        // uniformity on the vector unit.  fmax/fmin skip NaN operands, which is right for
+        // "any > iso" (NaN > iso is false, marching.cpp:498) but not for "all > iso": a NaN
+        // among samples that are otherwise all > iso shows up as a NaN sum.
+        const float mx = max3f(max3f(ra[0], ra[1], ra[2]), max3f(ra[3], rc[0], rc[1]), __builtin_fmaxf(rc[2], rc[3]));
+        const float mn = min3f(min3f(ra[0], ra[1], ra[2]), min3f(ra[3], rc[0], rc[1]), __builtin_fminf(rc[2], rc[3]));
+        gt = __ballot(mx > iso);
+        ge = __ballot(mn > iso);
+        hasnan = false;
+        if (__builtin_expect(ge == ~0ull, 0)) {
+            const float sm = ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((rc[0] + rc[1]) + (rc[2] + rc[3]));
+            hasnan = __ballot(sm != sm) != 0ull;
         }
-        const u32 ebits_any = (u32)(Eany >> j) & 3u, ebits_all = (u32)(Eall >> j) & 3u;
-        const bool none = !prevAny && !newAny && ebits_any == 0u;
-        const bool full = prevAll && newAll && ebits_all == 3u;
+    };
+    // wave masks of one sample row, computed inside the mixed path only: the empty volatile
+    // asm pins each compare to this branch (the compiler otherwise hoists all 16 v_cmp into
+    // every step) while the ballot result stays known-uniform (SGPR pair)
+    auto row_masks = [&](const float (&ra)[4], const float (&rc)[4], int row, u64 (&Ma)[5], u64 (&Mc)[5]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float va = ra[c], vc = rc[c];
+            asm volatile("" : "+v"(va), "+v"(vc));
+            Ma[c] = __ballot(va > iso);
+            Mc[c] = __ballot(vc > iso);
+        }
+        // index 4 = the lane's "x+4" sample = lane+1's sample 0; lane 63 takes column E.
+        // (The empty asm keeps the two halves apart: fused into one 64-bit funnel shift, which
+        // has no scalar form, the mask would land in VGPRs and could not feed v_addc's carry-in.)
+        u64 ta = (E0 >> row) << 63, tc2 = (E1 >> row) << 63;
+        asm("" : "+s"(ta), "+s"(tc2));
+        Ma[4] = (Ma[0] >> 1) | ta;
+        Mc[4] = (Mc[0] >> 1) | tc2;
+    };
 
+    auto step = [&](int j, float (&la)[4], float (&lc)[4], float (&ua)[4], float (&uc)[4]) {
+        u64 gtNew, geNew;
+        bool nanNew;
+        eval_row(readlane_f(yv, j + 1), ua, uc, gtNew, geNew, nanNew);
+        const u64 anyBits = gtNew | gtPrev | (((E0 | E1) >> j) & 3ull);
         u32 dw;
-        if (none) {
+        if (anyBits == 0ull) {
             dw = 0u;
-            haveAC = false;
-        } else if (full) {
-            dw = 0xFFFFFFFFu & vmask;
-            haveAC = false;
+        } else if ((geNew & gePrev) == ~0ull && !nanNew && !nanPrev && (((E0 & E1) >> j) & 3ull) == 3ull) {
+            dw = vmask;
         } else {
-            // wave masks of the 4 sample rows; index 4 = the lane's "x+4" sample = lane+1's sample 0
-            u64 B[5], D[5];
-            if (!haveAC) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    A[c] = __ballot(a[c] > iso);
-                    C[c] = __ballot(cc[c] > iso);
-                }
-                A[4] = (A[0] >> 1) | (((E0 >> j) & 1ull) << 63);
-                C[4] = (C[0] >> 1) | (((E1 >> j) & 1ull) << 63);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                B[c] = __ballot(b[c] > iso);
-                D[c] = __ballot(d[c] > iso);
-            }
-            B[4] = (B[0] >> 1) | (((E0 >> (j + 1)) & 1ull) << 63);
-            D[4] = (D[0] >> 1) | (((E1 >> (j + 1)) & 1ull) << 63);
-            // cube code bit i <-> corner i (marching.cpp:471-472, :497-505):
-            //   0:(x0,y0,z0)=A[c] 1:(x1,y0,z0)=A[c+1] 2:(x1,y1,z0)=B[c+1] 3:(x0,y1,z0)=B[c]
-            //   4:(x0,y0,z1)=C[c] 5:(x1,y0,z1)=C[c+1] 6:(x1,y1,z1)=D[c+1] 7:(x0,y1,z1)=D[c]
+            u64 LA[5], LC[5], UA[5], UC[5];  // wave masks of the lower / upper sample row, planes z / z+1
+            row_masks(la, lc, j, LA, LC);
+            row_masks(ua, uc, j + 1, UA, UC);
+            // cube code bit i <-> corner i (marching.cpp:471-472, :497-505), L = lower row, U = upper:
+            //   0:(x0,y0,z0)=LA[c] 1:(x1,y0,z0)=LA[c+1] 2:(x1,y1,z0)=UA[c+1] 3:(x0,y1,z0)=UA[c]
+            //   4:(x0,y0,z1)=LC[c] 5:(x1,y0,z1)=LC[c+1] 6:(x1,y1,z1)=UC[c+1] 7:(x0,y1,z1)=UC[c]
             dw = 0u;
 #pragma unroll
             for (int c = 3; c >= 0; --c) {
-                push_bit(dw, D[c]);
-                push_bit(dw, D[c + 1]);
-                push_bit(dw, C[c + 1]);
-                push_bit(dw, C[c]);
-                push_bit(dw, B[c]);
-                push_bit(dw, B[c + 1]);
-                push_bit(dw, A[c + 1]);
-                push_bit(dw, A[c]);
+                push_bit(dw, UC[c]);
+                push_bit(dw, UC[c + 1]);
+                push_bit(dw, LC[c + 1]);
+                push_bit(dw, LC[c]);
+                push_bit(dw, UA[c]);
+                push_bit(dw, UA[c + 1]);
+                push_bit(dw, LA[c + 1]);
+                push_bit(dw, LA[c]);
             }
             dw &= vmask;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                A[c] = B[c];
-                C[c] = D[c];
-            }
-            haveAC = true;
             // stage the lanes that may hold surface cells (dword neither all-0 nor all-1 bytes)
-            const u64 m = __ballot(dw != 0u && dw != 0xFFFFFFFFu);
+            const bool mixed = dw != 0u && dw != 0xFFFFFFFFu;
+            const u64 m = __ballot(mixed);
             if (m) {
-                if (nent + (u32)__builtin_popcountll(m) > MC_ENT_CAP) {
+                const u32 cnt = (u32)__builtin_popcountll(m);
+                if (nent + cnt > MC_ENT_CAP) {
                     mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
                     nent = 0;
                 }
-                if (dw != 0u && dw != 0xFFFFFFFFu) {
+                if (mixed) {
                     const u32 idx = nent + mask_rank(m);
                     ent_dw[idx] = dw;
                     ent_pos[idx] = (unsigned short)((j << 6) | lane);
                 }
-                nent += (u32)__builtin_popcountll(m);
+                nent += cnt;
             }
         }
-        if (x0 < n1) *(u32*)(rowp + (u64)j * p.pitch) = dw;
+        if (x0 < n1) *(u32*)(rowbase + xoff) = dw;
+        rowbase += p.pitch;
+        gtPrev = gtNew;
+        gePrev = geNew;
+        nanPrev = nanNew;
+    };
 
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            a[c] = b[c];
-            cc[c] = d[c];
-        }
-        prevAny = newAny;
-        prevAll = newAll;
+    eval_row(readlane_f(yv, 0), r0a, r0c, gtPrev, gePrev, nanPrev);
+    int j = 0;
+    for (; j + 1 < ny; j += 2) {
+        step(j, r0a, r0c, r1a, r1c);
+        step(j + 1, r1a, r1c, r0a, r0c);
     }
+    if (j < ny) step(j, r0a, r0c, r1a, r1c);
+
     if (nent) mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -491,7 +485,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
 
     const McParams p = *P;
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
     const u32 group = blockIdx.x * 4u + (u32)w;
     const u32 seg_first = group * 64u;
     if (seg_first >= p.nseg) return;
