@@ -339,6 +339,36 @@ std::string emit_hip(const Program& p) {
     return s;
 }
 
+bool finite_on_domain(const Program& p, double radius) {
+    const double LIMIT = 1e30;
+    std::vector<double> b(p.nodes.size(), 0.0);  // upper bound of |value|
+    for (size_t i = 0; i < p.nodes.size(); ++i) {
+        const Node& n = p.nodes[i];
+        double v;
+        switch (n.op) {
+        case NodeOp::CONST: v = std::fabs((double)n.cval); break;
+        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: v = radius; break;
+        case NodeOp::ADD: case NodeOp::SUB: v = b[n.a] + b[n.b]; break;
+        case NodeOp::MUL: v = b[n.a] * b[n.b]; break;
+        case NodeOp::NEG: v = b[n.a]; break;
+        case NodeOp::POWI:
+            if (n.ipow < 0) return false;
+            v = std::pow(b[n.a], (double)n.ipow);
+            break;
+        case NodeOp::DIV: {
+            const Node& d = p.nodes[n.b];
+            if (d.op != NodeOp::CONST || d.cval == 0.0f || !std::isfinite(d.cval)) return false;
+            v = b[n.a] / std::fabs((double)d.cval);
+            break;
+        }
+        default: return false;  // general pow
+        }
+        if (!(v < LIMIT)) return false;  // also rejects NaN / inf constants
+        b[i] = v * (1.0 + 1e-6) + 1e-30;  // rounding slack
+    }
+    return true;
+}
+
 float eval_host(const Program& p, float x, float y, float z) {
     std::vector<float> v(p.nodes.size());
     for (size_t i = 0; i < p.nodes.size(); ++i) {

@@ -57,6 +57,12 @@ std::string emit_hip(const Program& p);
 // Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
 float eval_host(const Program& p, float x, float y, float z);
 
+// Interval bound: true when |every intermediate value of f| < 1e30 for all |x|,|y|,|z| <= radius,
+// using only +, -, *, negation, literal non-negative integer powers and division by non-zero
+// constants.  Then no sample can be inf or NaN (no overflow, hence no inf-inf / 0*inf), and the
+// kernels may drop their NaN bookkeeping (MC_FINITE).
+bool finite_on_domain(const Program& p, double radius);
+
 // Power rule P1 (shared by constant folding, eval_host and -- as generated code -- the device).
 float pow_literal_int(float a, int n);
 float pow_general(float a, float b);

@@ -50,7 +50,9 @@ __device__ __forceinline__ float mc_pow_int(float a) {
     if (N < 0) r = 1.0 / r;
     return (float)r;
 }
-__device__ __forceinline__ float mc_pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
+// not inlined: the double-precision pow body is ~1k instructions; f may call it several times and
+// the kernels evaluate f at dozens of sites
+__device__ __attribute__((noinline)) float mc_pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
 
 //@@MC_F_BEGIN  (replaced by generated code when JIT-compiled)
 __device__ __forceinline__ float mc_f(float x, float y, float z) {
@@ -163,51 +165,87 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, int ix, in
 // One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer,
 // walked along y for up to 63 rows.  Every lattice sample of the two z planes is evaluated
 // once per tile row and the previous row's samples stay in registers, so a cell costs 2
-// evaluations instead of 8.  The kernel is bound by vector-instruction issue (a wave64 VALU
-// op occupies its SIMD for ~4 cycles; measured, profiles/), so the design minimises VALU ops:
+// evaluations instead of 8.  The kernel is bound by instruction issue, not by HBM (measured,
+// profiles/: a VOP3 op such as v_cmp->SGPR, v_max3 or v_addc costs ~4 cycles per wave on its
+// SIMD, a VOP2 add ~2.2, and scalar ops are not free either), so the design minimises
+// instructions per 256-cell step:
 //
-//  * Uniform steps (every corner of all 256 cells on one side of iso -- most of a volume) are
-//    recognised with a min/max tree over the lane's 8 new samples and two v_cmp, and store
-//    0x00000000 / 0xFFFFFFFF.  ~20 VALU ops per 256 cells.  (A mask-algebra version of this
-//    test cost ~50 scalar ops per step and made the kernel scalar-issue bound: the scalar
-//    unit is shared by the CU's four SIMDs.)
-//  * Mixed steps turn the 16 sample vectors into wave masks (v_cmp -> SGPR pair) and assemble
-//    the lane's four 8-bit cube codes into one dword with 32 carry-in adds.  Lanes whose dword is
-//    not 0 / ~0 append it to a small per-wave LDS list.
-//  * The expensive part -- triangle-count lookup, ambiguity test, per-segment prefix sums and
-//    the compact per-cell RECORDS the emit kernel consumes -- runs lane-parallel over that
-//    list once per tile (a tile has ~35 mixed dwords on a smooth surface) instead of
-//    wave-wide in each of its ~20 mixed steps.
-#define MC_ENT_CAP 256  // mixed dwords staged per wave before the record pass runs
+//  * Uniform steps (every corner of all 256 cells on one side of iso -- ~70 % of the steps
+//    of the 1024^3 sphere) are recognised with a min/max tree over the lane's 8 new samples
+//    and two v_cmp, and store 0x00000000 / 0xFFFFFFFF: ~20 VALU + ~10 SALU ops.
+//  * Mixed steps classify each LANE the same way with four more v_cmp (the lane's "x+4"
+//    neighbour column) and a little mask algebra: lanes whose 4 cells are all-below /
+//    all-above store 0 / ~0; the few remaining lanes (1-4 per step on a smooth surface) only
+//    note their position in a per-wave LDS list.
+//  * The expensive part -- assembling the 8-bit cube codes of those lanes, triangle-count
+//    lookup, ambiguity test, per-segment prefix sums and the compact per-cell RECORDS the
+//    emit kernel consumes -- runs lane-parallel over that list once per tile (a tile has ~35
+//    listed lanes on a smooth surface) instead of wave-wide in each of its ~20 mixed steps.
+#define MC_ENT_CAP 512  // (row, lane) positions staged per wave before the record pass runs
 
 struct McTileCtx {
-    int ch, y0, iz, lane;
+    int ch, y0, iz, lz, lane;
     u64 seg0;  // segment index of tile row 0; + nchunk per row
 };
 
-// lane-parallel pass over the staged mixed dwords (entries sorted by (row, lane))
+// lane-parallel pass over the staged positions (sorted by (row, lane)): one lane = one dword
+// of 4 cells whose corners are not all on one side of iso
 __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCtx& t, const unsigned short* s_lut,
-                                               const u32* ent_dw, const unsigned short* ent_pos, u32* seg_cnt, u32 nent,
-                                               u32* __restrict__ recs, int& carry_j, u32& carry_val) {
+                                               const unsigned short* ent_pos, u32* seg_cnt, u32 nent,
+                                               u8* __restrict__ codes, u32* __restrict__ recs, int& carry_j,
+                                               u32& carry_val) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const int n1 = p.n1;
+    const float* __restrict__ ax = p.axs;
+    const float* __restrict__ ay = p.axs + (n1 + 1);
+    const float* __restrict__ az = p.axs + 2 * (n1 + 1);
+    const float zk = az[t.iz], zk1 = az[t.iz + 1];
+    const float iso = p.iso;
     for (u32 e0 = 0; e0 < nent; e0 += 64u) {
         const u32 e = e0 + (u32)t.lane;
         const bool valid = e < nent;
-        const u32 dw = valid ? ent_dw[e] : 0u;
         const u32 pos = valid ? ent_pos[e] : 0xFFFFu;
-        const int j = (int)(pos >> 6), ln = (int)(pos & 63u);
+        const int j = valid ? (int)(pos >> 6) : 1023, ln = (int)(pos & 63u);
+        const int jj = valid ? j : 0;
+        const int x0 = t.ch * MC_SEG + ln * 4;
+        // the 20 lattice samples of the lane's 4 cells: same mc_f, same operands, same compare as
+        // the walk (marching.cpp:475-479, :497-505), so both agree on every shared sample
+        const float yl = ay[t.y0 + jj], yu = ay[t.y0 + jj + 1];
+        u32 sb = 0;  // bit (4*c + 2*r + pl): sample x0+c, row r (0 lower / 1 upper), plane pl
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float x = ax[min(x0 + c, n1)];
+            sb |= (mc_f(x, yl, zk) > iso ? 1u : 0u) << (4 * c + 0);
+            sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
+            sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
+            sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
+        }
+        // cube code bit i <-> corner i (marching.cpp:471-472): with s = nibble of sample c and
+        // n = nibble of sample c+1:  0:(x0,y0,z0)=s.0  1:(x1,y0,z0)=n.0  2:(x1,y1,z0)=n.2  3:(x0,y1,z0)=s.2
+        //                            4:(x0,y0,z1)=s.1  5:(x1,y0,z1)=n.1  6:(x1,y1,z1)=n.3  7:(x0,y1,z1)=s.3
+        u32 dw = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32 sN = (sb >> (4 * c)) & 0xFu, nN = (sb >> (4 * c + 4)) & 0xFu;
+            const u32 code = (sN & 1u) | ((nN & 1u) << 1) | (((nN >> 2) & 1u) << 2) | (((sN >> 2) & 1u) << 3) |
+                             (((sN >> 1) & 1u) << 4) | (((nN >> 1) & 1u) << 5) | (((nN >> 3) & 1u) << 6) |
+                             (((sN >> 3) & 1u) << 7);
+            if (x0 + c < n1) dw |= code << (8 * c);
+        }
+        if (valid && x0 < n1) *(u32*)(codes + ((u64)t.lz * n1 + t.y0 + j) * p.pitch + x0) = dw;
+
         // per cell: triangle count and ambiguity flip; meta nibble c = count | flip<<3
         u32 meta = 0, packed = 0;  // packed = triangles | active cells << 16 of this entry
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int code = (dw >> (8 * c)) & 0xFF;
+            const int code = valid ? (int)((dw >> (8 * c)) & 0xFF) : 0;
             if (code != 0 && code != 255) {
                 const u32 lut = s_lut[code];
                 u32 nt = lut & 0xFFu, flip = 0;
                 const int face = (int)(lut >> 8);
                 if (face != 0xFF)
-                    if (amb_flip(p, face, t.ch * MC_SEG + ln * 4 + c, t.y0 + j, t.iz)) {
+                    if (amb_flip(p, face, x0 + c, t.y0 + j, t.iz)) {
                         nt = s_lut[255 - code] & 0xFFu;
                         flip = 1;
                     }
@@ -254,7 +292,6 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
 extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
                                                                u32* __restrict__ segcnt, u32* __restrict__ recs) {
     __shared__ unsigned short s_lut[256];  // triangle count | ambiguity face << 8
-    __shared__ u32 s_ent_dw[4][MC_ENT_CAP];
     __shared__ unsigned short s_ent_pos[4][MC_ENT_CAP];
     __shared__ u32 s_segcnt[4][64];
     s_lut[threadIdx.x] = (unsigned short)(c_tri_count[threadIdx.x] | (c_amb_face[threadIdx.x] << 8));
@@ -279,7 +316,6 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const int ny = min(p.tile_h, n1 - y0);
     const float iso = p.iso;
 
-    u32* ent_dw = s_ent_dw[w];
     unsigned short* ent_pos = s_ent_pos[w];
     u32* seg_cnt = s_segcnt[w];
     seg_cnt[lane] = 0u;
@@ -298,128 +334,97 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const float zk = az[iz], zk1 = az[iz + 1];
 
     // sample column x = xe for the tile's 64 sample rows (lane = row): bit j of E0 / E1 is the
-    // "x+4" neighbour of lane 63 in row j
+    // "x+4" neighbour of lane 63 in row j.  ENone / EFull bit j: both rows j, j+1 of both planes
+    // are below / above iso in that column.
     const u64 E0 = __ballot(mc_f(xe, yv, zk) > iso);
     const u64 E1 = __ballot(mc_f(xe, yv, zk1) > iso);
+    const u64 ENone = ~((E0 | E1) | ((E0 | E1) >> 1));
+    const u64 EFull = (E0 & E1) & ((E0 & E1) >> 1);
 
-    u32 vmask = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (x0 + c < n1) vmask |= 0xFFu << (8 * c);
+    const u32 vmask = (x0 + 3 < n1) ? 0xFFFFFFFFu : (x0 + 2 < n1) ? 0x00FFFFFFu : (x0 + 1 < n1) ? 0x0000FFFFu
+                      : (x0 < n1) ? 0x000000FFu : 0u;
 
     McTileCtx tc;
     tc.ch = ch;
     tc.y0 = y0;
     tc.iz = iz;
+    tc.lz = lz;
     tc.lane = lane;
     tc.seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;
     u32 nent = 0;
     int carry_j = -1;
     u32 carry_val = 0;
 
-    // Two sample-row register sets (plane z / plane z+1 each) and two wave-mask sets ping-pong
-    // between "lower row" and "upper row" so the walk never copies registers.
+    // Two sample-row register sets (plane z / plane z+1 each) ping-pong between "lower row" and
+    // "upper row" so the walk never copies registers.
     float r0a[4], r0c[4], r1a[4], r1c[4];
-    u64 gtPrev, gePrev;    // ballots of the lower row: max-of-lane > iso, min-of-lane > iso
-    bool nanPrev;          // lower row has a NaN among samples that otherwise all exceed iso
+    u64 gtPrev, gePrev;  // lower row, per lane: some sample > iso / every sample > iso
     // row base of the code plane as a wave-uniform pointer + 32-bit lane offset (saddr store)
     u8* __restrict__ rowbase = codes + ((u64)lz * n1 + y0) * p.pitch;
     const u32 xoff = (u32)x0;
 
-    auto eval_row = [&](float y, float (&ra)[4], float (&rc)[4], u64& gt, u64& ge, bool& hasnan) {
+    auto eval_row = [&](float y, float (&ra)[4], float (&rc)[4], u64& gt, u64& ge) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             ra[c] = mc_f(xs[c], y, zk);
             rc[c] = mc_f(xs[c], y, zk1);
         }
-        // uniformity on the vector unit.  fmax/fmin skip NaN operands, which is right for
-        // "any > iso" (NaN > iso is false, marching.cpp:498) but not for "all > iso": a NaN
-        // among samples that are otherwise all > iso shows up as a NaN sum.
+        // per-lane uniformity on the vector unit.  fmax/fmin skip NaN operands, which is right
+        // for "some sample > iso" (NaN > iso is false, marching.cpp:498) but not for "every
+        // sample > iso": a NaN among samples that otherwise all exceed iso shows as a NaN sum.
         const float mx = max3f(max3f(ra[0], ra[1], ra[2]), max3f(ra[3], rc[0], rc[1]), __builtin_fmaxf(rc[2], rc[3]));
         const float mn = min3f(min3f(ra[0], ra[1], ra[2]), min3f(ra[3], rc[0], rc[1]), __builtin_fminf(rc[2], rc[3]));
         gt = __ballot(mx > iso);
         ge = __ballot(mn > iso);
-        hasnan = false;
-        if (__builtin_expect(ge == ~0ull, 0)) {
+#ifndef MC_FINITE  // MC_FINITE: the expression compiler proved f finite on the whole domain
+        if (ge != 0ull) {
             const float sm = ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((rc[0] + rc[1]) + (rc[2] + rc[3]));
-            hasnan = __ballot(sm != sm) != 0ull;
+            ge &= ~__ballot(sm != sm);
         }
-    };
-    // wave masks of one sample row, computed inside the mixed path only: the empty volatile
-    // asm pins each compare to this branch (the compiler otherwise hoists all 16 v_cmp into
-    // every step) while the ballot result stays known-uniform (SGPR pair)
-    auto row_masks = [&](const float (&ra)[4], const float (&rc)[4], int row, u64 (&Ma)[5], u64 (&Mc)[5]) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float va = ra[c], vc = rc[c];
-            asm volatile("" : "+v"(va), "+v"(vc));
-            Ma[c] = __ballot(va > iso);
-            Mc[c] = __ballot(vc > iso);
-        }
-        // index 4 = the lane's "x+4" sample = lane+1's sample 0; lane 63 takes column E.
-        // (The empty asm keeps the two halves apart: fused into one 64-bit funnel shift, which
-        // has no scalar form, the mask would land in VGPRs and could not feed v_addc's carry-in.)
-        u64 ta = (E0 >> row) << 63, tc2 = (E1 >> row) << 63;
-        asm("" : "+s"(ta), "+s"(tc2));
-        Ma[4] = (Ma[0] >> 1) | ta;
-        Mc[4] = (Mc[0] >> 1) | tc2;
+#endif
     };
 
     auto step = [&](int j, float (&la)[4], float (&lc)[4], float (&ua)[4], float (&uc)[4]) {
         u64 gtNew, geNew;
-        bool nanNew;
-        eval_row(readlane_f(yv, j + 1), ua, uc, gtNew, geNew, nanNew);
-        const u64 anyBits = gtNew | gtPrev | (((E0 | E1) >> j) & 3ull);
-        u32 dw;
-        if (anyBits == 0ull) {
-            dw = 0u;
-        } else if ((geNew & gePrev) == ~0ull && !nanNew && !nanPrev && (((E0 & E1) >> j) & 3ull) == 3ull) {
-            dw = vmask;
+        eval_row(readlane_f(yv, j + 1), ua, uc, gtNew, geNew);
+        const u64 anyOwn = gtNew | gtPrev, allOwn = geNew & gePrev;
+        const bool eNone = (ENone >> j) & 1ull, eFull = (EFull >> j) & 1ull;
+        if (anyOwn == 0ull && eNone) {
+            if (x0 < n1) *(u32*)(rowbase + xoff) = 0u;
+        } else if (allOwn == ~0ull && eFull) {
+            if (x0 < n1) *(u32*)(rowbase + xoff) = vmask;
         } else {
-            u64 LA[5], LC[5], UA[5], UC[5];  // wave masks of the lower / upper sample row, planes z / z+1
-            row_masks(la, lc, j, LA, LC);
-            row_masks(ua, uc, j + 1, UA, UC);
-            // cube code bit i <-> corner i (marching.cpp:471-472, :497-505), L = lower row, U = upper:
-            //   0:(x0,y0,z0)=LA[c] 1:(x1,y0,z0)=LA[c+1] 2:(x1,y1,z0)=UA[c+1] 3:(x0,y1,z0)=UA[c]
-            //   4:(x0,y0,z1)=LC[c] 5:(x1,y0,z1)=LC[c+1] 6:(x1,y1,z1)=UC[c+1] 7:(x0,y1,z1)=UC[c]
-            dw = 0u;
-#pragma unroll
-            for (int c = 3; c >= 0; --c) {
-                push_bit(dw, UC[c]);
-                push_bit(dw, UC[c + 1]);
-                push_bit(dw, LC[c + 1]);
-                push_bit(dw, LC[c]);
-                push_bit(dw, UA[c]);
-                push_bit(dw, UA[c + 1]);
-                push_bit(dw, LA[c + 1]);
-                push_bit(dw, LA[c]);
-            }
-            dw &= vmask;
-            // stage the lanes that may hold surface cells (dword neither all-0 nor all-1 bytes)
-            const bool mixed = dw != 0u && dw != 0xFFFFFFFFu;
-            const u64 m = __ballot(mixed);
-            if (m) {
-                const u32 cnt = (u32)__builtin_popcountll(m);
+            // per-lane classification: the lane's x+4 neighbour column is lane+1's sample 0
+            // (lane 63: column E).  The empty asm pins the four compares to this branch.
+            float l0 = la[0], l1 = lc[0], u0 = ua[0], u1 = uc[0];
+            asm volatile("" : "+v"(l0), "+v"(l1), "+v"(u0), "+v"(u1));
+            const u64 n0 = __ballot(l0 > iso), n1m = __ballot(l1 > iso), n2 = __ballot(u0 > iso), n3 = __ballot(u1 > iso);
+            u64 topAny = (~ENone >> j) << 63, topAll = (EFull >> j) << 63;
+            asm("" : "+s"(topAny), "+s"(topAll));  // keep the halves apart (no 64-bit funnel shift on the SALU)
+            const u64 nbAny = ((n0 | n1m | n2 | n3) >> 1) | topAny;
+            const u64 nbAll = ((n0 & n1m & n2 & n3) >> 1) | topAll;
+            const u64 laneAny = anyOwn | nbAny;
+            const u64 laneAll = allOwn & nbAll;
+            const u64 mixedL = laneAny & ~laneAll;  // lanes with corners on both sides of iso
+            const u32 dw = __builtin_amdgcn_inverse_ballot_w64(laneAll) ? vmask : 0u;
+            if (!__builtin_amdgcn_inverse_ballot_w64(mixedL) && x0 < n1) *(u32*)(rowbase + xoff) = dw;
+            if (mixedL) {
+                const u32 cnt = (u32)__builtin_popcountll(mixedL);
                 if (nent + cnt > MC_ENT_CAP) {
-                    mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
+                    mc_record_pass(p, tc, s_lut, ent_pos, seg_cnt, nent, codes, recs, carry_j, carry_val);
                     nent = 0;
                 }
-                if (mixed) {
-                    const u32 idx = nent + mask_rank(m);
-                    ent_dw[idx] = dw;
-                    ent_pos[idx] = (unsigned short)((j << 6) | lane);
-                }
+                if (__builtin_amdgcn_inverse_ballot_w64(mixedL))
+                    ent_pos[nent + mask_rank(mixedL)] = (unsigned short)((j << 6) | lane);
                 nent += cnt;
             }
         }
-        if (x0 < n1) *(u32*)(rowbase + xoff) = dw;
         rowbase += p.pitch;
         gtPrev = gtNew;
         gePrev = geNew;
-        nanPrev = nanNew;
     };
 
-    eval_row(readlane_f(yv, 0), r0a, r0c, gtPrev, gePrev, nanPrev);
+    eval_row(readlane_f(yv, 0), r0a, r0c, gtPrev, gePrev);
     int j = 0;
     for (; j + 1 < ny; j += 2) {
         step(j, r0a, r0c, r1a, r1c);
@@ -427,7 +432,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     }
     if (j < ny) step(j, r0a, r0c, r1a, r1c);
 
-    if (nent) mc_record_pass(p, tc, s_lut, ent_dw, ent_pos, seg_cnt, nent, recs, carry_j, carry_val);
+    if (nent) mc_record_pass(p, tc, s_lut, ent_pos, seg_cnt, nent, codes, recs, carry_j, carry_val);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < ny) segcnt[tc.seg0 + (u64)lane * p.nchunk] = seg_cnt[lane];
