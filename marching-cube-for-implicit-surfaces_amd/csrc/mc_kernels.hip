@@ -384,15 +384,26 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
 #endif
     };
 
+    // Code stores go through a buffer descriptor over the valid bytes of ONE row, rebuilt per
+    // step by advancing its (scalar) base: lanes beyond the end of the row are dropped by the
+    // hardware range check instead of by exec-mask juggling, and the address needs no vector
+    // arithmetic.  (The range check covers voffset + soffset, so the row cannot advance through
+    // soffset: measured -- such stores are dropped from the second row on.)
+    const int rowbytes = (int)(((u32)n1 + 3u) & ~3u);
+
     auto step = [&](int j, float (&la)[4], float (&lc)[4], float (&ua)[4], float (&uc)[4]) {
         u64 gtNew, geNew;
         eval_row(readlane_f(yv, j + 1), ua, uc, gtNew, geNew);
         const u64 anyOwn = gtNew | gtPrev, allOwn = geNew & gePrev;
-        const bool eNone = (ENone >> j) & 1ull, eFull = (EFull >> j) & 1ull;
-        if (anyOwn == 0ull && eNone) {
-            if (x0 < n1) *(u32*)(rowbase + xoff) = 0u;
-        } else if (allOwn == ~0ull && eFull) {
-            if (x0 < n1) *(u32*)(rowbase + xoff) = vmask;
+        const bool none = anyOwn == 0ull && ((ENone >> j) & 1ull);
+        const bool full = allOwn == ~0ull && ((EFull >> j) & 1ull);
+        if (__builtin_expect(none || full, 1)) {
+#ifdef MC_STORE_GLOBAL
+            if (x0 < n1) *(u32*)(rowbase + xoff) = full ? vmask : 0u;
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(full ? vmask : 0u,
+                                                  __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, rowbytes, 0x00020000), xoff, 0, 0);
+#endif
         } else {
             // per-lane classification: the lane's x+4 neighbour column is lane+1's sample 0
             // (lane 63: column E).  The empty asm pins the four compares to this branch.
@@ -403,11 +414,16 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
             asm("" : "+s"(topAny), "+s"(topAll));  // keep the halves apart (no 64-bit funnel shift on the SALU)
             const u64 nbAny = ((n0 | n1m | n2 | n3) >> 1) | topAny;
             const u64 nbAll = ((n0 & n1m & n2 & n3) >> 1) | topAll;
-            const u64 laneAny = anyOwn | nbAny;
             const u64 laneAll = allOwn & nbAll;
-            const u64 mixedL = laneAny & ~laneAll;  // lanes with corners on both sides of iso
+            const u64 mixedL = (anyOwn | nbAny) & ~laneAll;  // lanes with corners on both sides of iso
             const u32 dw = __builtin_amdgcn_inverse_ballot_w64(laneAll) ? vmask : 0u;
+#ifdef MC_STORE_GLOBAL
             if (!__builtin_amdgcn_inverse_ballot_w64(mixedL) && x0 < n1) *(u32*)(rowbase + xoff) = dw;
+#else
+            if (!__builtin_amdgcn_inverse_ballot_w64(mixedL))
+                __builtin_amdgcn_raw_buffer_store_b32(dw, __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, rowbytes, 0x00020000),
+                                                      xoff, 0, 0);
+#endif
             if (mixedL) {
                 const u32 cnt = (u32)__builtin_popcountll(mixedL);
                 if (nent + cnt > MC_ENT_CAP) {
