@@ -36,7 +36,9 @@ def cpu_baseline(eq, step, n1, budget_s=15.0):
     """Oracle (port of the reference) on the host cores, on a bounded slab of the same grid."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import pyoracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box hands this job a 16-CPU share whatever the affinity mask says
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
+                int(os.environ.get("BENCH_CPU_THREADS", "16")))
     mid = n1 // 2
     t0 = time.perf_counter()
     probe_layers = max(1, min(cores, n1 - mid))
@@ -75,8 +77,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # BENCH_BACKEND=gloo + BENCH_SINGLE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.gpus != 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
@@ -87,12 +96,13 @@ def main():
     zb, ze = mc_amd.shard_layers(n1, world, rank)
     flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
     ctx = mc_amd.Context(local_rank)
-    counts_dev = torch.zeros(world, dtype=torch.int64, device="cuda") if world > 1 else None
+    cdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if world > 1 else None
 
     def one_step():
         r = ctx.march(eq, step, 0.0, flags=flags, z_begin=zb, z_end=ze)
         if world > 1:  # the path's one real exchange: per-rank triangle counts -> global offsets
-            mine = torch.tensor([r.n_tris], dtype=torch.int64, device="cuda")
+            mine = torch.tensor([r.n_tris], dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(counts_dev, mine)
         return r
 
@@ -115,7 +125,7 @@ def main():
 
     stats = torch.tensor([elapsed, float(r.n_cells), float(r.n_tris), *kt], dtype=torch.float64)
     if world > 1:
-        stats = stats.cuda()
+        stats = stats.to(cdev)
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()

@@ -1,0 +1,49 @@
+// facade_demo.cpp -- the reference's documented usage (Source/marching_test_drawer.h:7-15,
+// Source/main.cpp:11-14) written against include/mc_marching.hpp.  Prints counts and the FNV-1a
+// fingerprint of the triangle soup so tests/test_facade.py can compare with the fingerprints
+// SURVEY.md section 4 recorded from the unmodified reference.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "mc_marching.hpp"
+
+using namespace mc_amd;
+
+int main(int argc, char** argv) {
+    const char* eq = argc > 1 ? argv[1] : "x^2+y^2+z^2-1";
+    const int grid_res = argc > 2 ? atoi(argv[2]) : 32;
+    const float iso = argc > 3 ? (float)atof(argv[3]) : 0.0f;
+    try {
+        Context ctx(0);
+        Evaluator evaluator;                 // default equation "x+y" (evaluator.cpp:6-8)
+        if (!evaluator.set_equation(eq)) {
+            printf("parse_error\n");
+            return 2;
+        }
+        if (evaluator.set_equation("sin(x)")) return 3;      // rejected: the previous equation stays
+        Marching march_maker(ctx);
+        march_maker.set_evaluator(&evaluator);
+        if (march_maker.set_grid_step_size(0.6f)) return 4;  // outside [0.001, 0.5]
+        march_maker.set_grid_step_size(2.0f / (float)grid_res);
+        march_maker.set_surface_constant(iso);
+        if (!march_maker.recalculate()) {
+            printf("error: %s\n", march_maker.last_error().c_str());
+            return 5;
+        }
+        const Poly_Data* pd = march_maker.get_poly_data();
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(pd->vertex_list.data());
+        for (size_t i = 0; i < pd->vertex_list.size() * sizeof(float); ++i) {
+            h ^= b[i];
+            h *= 1099511628211ull;
+        }
+        printf("cells_per_axis=%d tris=%zu verts=%zu fnv_soup=%016llx f(1,2,3)=%g\n", march_maker.last_result().cells_per_axis,
+               pd->tri_list.size() / 3, pd->vertex_list.size() / 3, (unsigned long long)h, evaluator.evaluate(ctx, 1, 2, 3));
+    } catch (const std::exception& e) {
+        printf("exception: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

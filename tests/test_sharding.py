@@ -1,0 +1,76 @@
+"""Z-slab sharding across ranks (one process per GPU).  CPU: world_size-2 gloo run of the host
+logic with the oracle standing in for the device (test infrastructure); GPU: two ranks sharing
+the one GPU of the box run the real bench path with a gloo rendezvous."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import EQ, ROOT
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import mc_amd, pyoracle as orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(24))
+n1 = mc_amd.cells_per_axis(step)
+zb, ze = mc_amd.shard_layers(n1, world, rank)
+m = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=orc.WANT_CODES | orc.WANT_SOUP, z_begin=zb, z_end=ze, nthreads=2)
+counts = torch.zeros(world, dtype=torch.int64)
+dist.all_gather_into_tensor(counts, torch.tensor([m.n_tris], dtype=torch.int64))
+offsets, total = mc_amd.exclusive_offsets(counts.tolist())
+# every rank writes its slab at its offset of a shared result; rank 0 checks against the unsharded sweep
+soup = torch.zeros(total * 9, dtype=torch.float32)
+soup[offsets[rank] * 9:(offsets[rank] + m.n_tris) * 9] = torch.from_numpy(m.soup.reshape(-1))
+dist.all_reduce(soup)   # disjoint ranges: a sum is a concatenation
+if rank == 0:
+    whole = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=orc.WANT_SOUP, nthreads=2)
+    assert total == whole.n_tris, (total, whole.n_tris)
+    assert np.array_equal(soup.numpy().view(np.uint32), whole.soup.reshape(-1).view(np.uint32))
+    print("SHARD_OK", total, offsets)
+dist.destroy_process_group()
+'''
+
+
+def test_shard_layers_cover_and_order(mc):
+    for n in (1, 5, 33, 257, 1025, 2001):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [mc.shard_layers(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert mc.exclusive_offsets([3, 0, 7]) == ([0, 3, 3], 10)
+
+
+def test_two_rank_gloo_sharded_sweep(tmp_path):
+    """world_size 2 on CPU: slabs + all-gathered counts + offsets reproduce the unsharded order."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", str(script), str(ROOT)], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "SHARD_OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path (slabs, count all-gather, max-over-ranks timing) with 2 ranks sharing GPU 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29534", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+                        "1", "--grid-res", "256"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["triangles"] == 617180 and d["config"]["cells"] == 257 ** 3
+    assert d["scaling"] == "strong" and d["value"] > 0
