@@ -30,6 +30,19 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TRAFFIC_PROFILE = ROOT / "profiles" / "r01_pmc_traffic_sphere1024.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic(kernel, workload_ok):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None if the
+    workload differs from the profiled one."""
+    if not workload_ok or not TRAFFIC_PROFILE.exists():
+        return None
+    try:
+        return int(json.loads(TRAFFIC_PROFILE.read_text())[kernel]["hbm_bytes_per_launch_fetch_x2"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(eq, step, n1, budget_s=15.0):
@@ -161,7 +174,10 @@ def main():
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
                           "gpu_total": round(ms_tot, 4)},
             "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("mc_classify", world == 1 and args.grid_res == 1024 and
+                                                eq == "x^2+y^2+z^2-1" and not args.no_normals),
+                         "traffic_source": "profiles/r01_pmc_traffic_sphere1024.json (rocprofv3 --pmc, per launch)",
                          "algorithmic_bytes_per_launch": int(cls_bytes)},
             "pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(pipe_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(pipe_bytes),
