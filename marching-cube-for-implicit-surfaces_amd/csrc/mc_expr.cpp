@@ -369,6 +369,112 @@ bool finite_on_domain(const Program& p, double radius) {
     return true;
 }
 
+std::string emit_hip_interval(const Program& p) {
+    std::string s;
+    char buf[512];
+    s += "__device__ __forceinline__ void mc_f_iv(float xl, float xh, float yl, float yh, float zl, float zh, float& lo, float& hi) {\n";
+    s += "    (void)xl; (void)xh; (void)yl; (void)yh; (void)zl; (void)zh;\n";
+    auto L = [&](int id) -> std::string {
+        const Node& n = p.nodes[id];
+        if (n.op == NodeOp::VARX) return "xl";
+        if (n.op == NodeOp::VARY) return "yl";
+        if (n.op == NodeOp::VARZ) return "zl";
+        std::snprintf(buf, sizeof buf, "l%d", id);
+        return buf;
+    };
+    auto H = [&](int id) -> std::string {
+        const Node& n = p.nodes[id];
+        if (n.op == NodeOp::VARX) return "xh";
+        if (n.op == NodeOp::VARY) return "yh";
+        if (n.op == NodeOp::VARZ) return "zh";
+        std::snprintf(buf, sizeof buf, "h%d", id);
+        return buf;
+    };
+    auto cst = [&](float v) -> std::string {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        std::snprintf(buf, sizeof buf, "__uint_as_float(0x%08xu)", u);
+        return buf;
+    };
+    for (size_t i = 0; i < p.nodes.size(); ++i) {
+        const Node& n = p.nodes[i];
+        const std::string l = L((int)i), h = H((int)i);
+        std::string lo, hi, pre;
+        switch (n.op) {
+        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: continue;
+        case NodeOp::CONST: lo = hi = cst(n.cval); break;
+        case NodeOp::ADD: lo = L(n.a) + " + " + L(n.b); hi = H(n.a) + " + " + H(n.b); break;
+        case NodeOp::SUB: lo = L(n.a) + " - " + H(n.b); hi = H(n.a) + " - " + L(n.b); break;
+        case NodeOp::NEG: lo = "-" + H(n.a); hi = "-" + L(n.a); break;
+        case NodeOp::MUL: {
+            const Node& A = p.nodes[n.a];
+            const Node& B = p.nodes[n.b];
+            if (n.a == n.b) {  // square: |x| in [mn, mx]
+                pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
+                      "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
+                      std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
+                      " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
+                      std::to_string(i) + "b);\n";
+                lo = "q" + std::to_string(i) + "n * q" + std::to_string(i) + "n";
+                hi = "q" + std::to_string(i) + "m * q" + std::to_string(i) + "m";
+            } else if (A.op == NodeOp::CONST || B.op == NodeOp::CONST) {
+                const bool a_const = A.op == NodeOp::CONST;
+                const float c = a_const ? A.cval : B.cval;
+                const int v = a_const ? n.b : n.a;
+                // keep the operand order of mc_f (a * b) so both round identically
+                auto prod = [&](const std::string& x) { return a_const ? cst(c) + " * " + x : x + " * " + cst(c); };
+                if (c >= 0.0f) { lo = prod(L(v)); hi = prod(H(v)); }
+                else { lo = prod(H(v)); hi = prod(L(v)); }
+            } else {
+                const std::string t = "p" + std::to_string(i);
+                pre = "    const float " + t + "a = " + L(n.a) + " * " + L(n.b) + ", " + t + "b = " + L(n.a) + " * " + H(n.b) + ", " +
+                      t + "c = " + H(n.a) + " * " + L(n.b) + ", " + t + "d = " + H(n.a) + " * " + H(n.b) + ";\n";
+                lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
+                hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
+            }
+            break;
+        }
+        case NodeOp::DIV: {
+            const Node& B = p.nodes[n.b];
+            if (B.op != NodeOp::CONST || B.cval == 0.0f) return std::string();
+            if (B.cval > 0.0f) { lo = L(n.a) + " / " + cst(B.cval); hi = H(n.a) + " / " + cst(B.cval); }
+            else { lo = H(n.a) + " / " + cst(B.cval); hi = L(n.a) + " / " + cst(B.cval); }
+            break;
+        }
+        case NodeOp::POWI: {
+            if (n.ipow < 2) return std::string();
+            std::snprintf(buf, sizeof buf, "mc_pow_int<%d>", n.ipow);
+            const std::string pw = buf;
+            if (n.ipow % 2 == 0) {
+                pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
+                      "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
+                      std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
+                      " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
+                      std::to_string(i) + "b);\n";
+                if (n.ipow == 2) {
+                    lo = "q" + std::to_string(i) + "n * q" + std::to_string(i) + "n";
+                    hi = "q" + std::to_string(i) + "m * q" + std::to_string(i) + "m";
+                } else {
+                    lo = pw + "(q" + std::to_string(i) + "n)";
+                    hi = pw + "(q" + std::to_string(i) + "m)";
+                }
+            } else {  // odd power: monotone increasing, also as computed (product chain of same-sign factors)
+                lo = pw + "(" + L(n.a) + ")";
+                hi = pw + "(" + H(n.a) + ")";
+            }
+            break;
+        }
+        default: return std::string();  // general pow
+        }
+        s += pre;
+        s += "    const float " + l + " = " + lo + ";\n";
+        if (n.op == NodeOp::CONST) s += "    const float " + h + " = " + l + ";\n";
+        else s += "    const float " + h + " = " + hi + ";\n";
+    }
+    s += "    lo = " + L(p.root) + ";\n    hi = " + H(p.root) + ";\n}\n";
+    return s;
+}
+
 float eval_host(const Program& p, float x, float y, float z) {
     std::vector<float> v(p.nodes.size());
     for (size_t i = 0; i < p.nodes.size(); ++i) {

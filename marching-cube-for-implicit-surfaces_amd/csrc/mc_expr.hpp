@@ -54,6 +54,14 @@ CompileStatus compile(const std::string& eq, Program& out, std::string& err);
 // HIP source of `__device__ __forceinline__ float mc_f(float x, float y, float z)`.
 std::string emit_hip(const Program& p);
 
+// HIP source of `mc_f_iv(xl,xh,yl,yh,zl,zh, lo, hi)`: an enclosure [lo,hi] of every value mc_f
+// COMPUTES for points of the box.  Each IEEE round-to-nearest operation is monotone, so interval
+// arithmetic whose endpoints are rounded the same way encloses the computed (not just the real)
+// values exactly -- no widening needed.  Only valid for programs that pass finite_on_domain()
+// (no NaN / inf can arise); the classify kernel uses it to prove whole rows of cells uniform
+// without sampling them.  Returns "" when the program uses an operation it cannot bound.
+std::string emit_hip_interval(const Program& p);
+
 // Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
 float eval_host(const Program& p, float x, float y, float z);
 

@@ -263,3 +263,20 @@ def test_sphere_1024_properties(mc, ctx):
     sub = p[: 3 * 200000]
     _, counts = np.unique(sub.view([("", np.float32)] * 3), return_counts=True)
     assert counts.mean() > 3
+
+
+@pytest.mark.parametrize("name,n,iso", [("sphere", 96, 0.0), ("eq3", 96, 0.0), ("eq8", 80, 0.0), ("eq2", 64, 0.0),
+                                        ("eq6", 64, 0.0), ("goursat", 96, -0.4), ("ui_default", 40, 0.0)])
+def test_interval_row_culling_is_exact(mc, ctx, name, n, iso, monkeypatch):
+    """K1 proves rows uniform with interval arithmetic (mc_f_iv) and skips sampling them; a build
+    with the culling compiled out (MC_NO_CULL) must give byte-identical codes and vertices."""
+    a = ctx.march(EQ[name], step_of(n), iso)
+    ca, va = a.codes(), a.vertices()
+    monkeypatch.setenv("MC_JIT_EXTRA", "#define MC_NO_CULL 1")
+    plain = mc.Context(0)     # a fresh context: compiled kernels are cached per context
+    try:
+        b = plain.march(EQ[name], step_of(n), iso)
+        assert np.array_equal(ca, b.codes())
+        assert np.array_equal(u32(va), u32(b.vertices()))
+    finally:
+        plain.close()
