@@ -372,9 +372,10 @@ static int grad_normal(orc_ctx *c, const float p[3], float h, float n[3], int *o
     g[2] = a - b;
     float len = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
     if (len > 0.0f && !isinf(len)) {
-        n[0] = g[0] / len;
-        n[1] = g[1] / len;
-        n[2] = g[2] / len;
+        const float inv = 1.0f / len;
+        n[0] = g[0] * inv;
+        n[1] = g[1] * inv;
+        n[2] = g[2] * inv;
         *okflag = 1;
     } else {
         *okflag = 0;
@@ -465,9 +466,10 @@ static int cell(orc_ctx *c, orc_layer *L, int want, const float *ax, int ix, int
                                        e1[0] * e2[1] - e1[1] * e2[0]};
                         float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
                         if (l > 0.0f && !isinf(l)) {
-                            fn[0] = cr[0] / l;
-                            fn[1] = cr[1] / l;
-                            fn[2] = cr[2] / l;
+                            const float inv = 1.0f / l;
+                            fn[0] = cr[0] * inv;
+                            fn[1] = cr[1] * inv;
+                            fn[2] = cr[2] * inv;
                         }
                         have_fn = 1;
                     }
