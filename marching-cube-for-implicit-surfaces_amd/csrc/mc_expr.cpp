@@ -1,6 +1,7 @@
 // mc_expr.cpp -- see mc_expr.hpp.  Compile with -ffp-contract=off.
 #include "mc_expr.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -339,32 +340,70 @@ std::string emit_hip(const Program& p) {
     return s;
 }
 
+// Interval analysis of the DAG over the whole domain box [-radius, radius]^3, in double with a
+// relative widening that covers the float roundings.  false as soon as a value could be inf /
+// NaN: a bound >= 1e30, a division or negative power whose base interval does not stay clear of
+// zero, or a general (non literal-integer) power.
 bool finite_on_domain(const Program& p, double radius) {
-    const double LIMIT = 1e30;
-    std::vector<double> b(p.nodes.size(), 0.0);  // upper bound of |value|
+    const double LIMIT = 1e30, TINY = 1e-30;
+    std::vector<double> lo(p.nodes.size(), 0.0), hi(p.nodes.size(), 0.0);
+    auto mulrange = [](double al, double ah, double bl, double bh, double& l, double& h) {
+        const double c[4] = {al * bl, al * bh, ah * bl, ah * bh};
+        l = std::min(std::min(c[0], c[1]), std::min(c[2], c[3]));
+        h = std::max(std::max(c[0], c[1]), std::max(c[2], c[3]));
+    };
+    auto powrange = [](double al, double ah, int n, double& l, double& h) {  // n >= 1
+        if (n % 2 == 0) {
+            const double m = std::max(std::fabs(al), std::fabs(ah));
+            const double k = (al <= 0.0 && ah >= 0.0) ? 0.0 : std::min(std::fabs(al), std::fabs(ah));
+            l = std::pow(k, n);
+            h = std::pow(m, n);
+        } else {
+            l = std::pow(al, n);
+            h = std::pow(ah, n);
+        }
+    };
     for (size_t i = 0; i < p.nodes.size(); ++i) {
         const Node& n = p.nodes[i];
-        double v;
+        double l, h;
         switch (n.op) {
-        case NodeOp::CONST: v = std::fabs((double)n.cval); break;
-        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: v = radius; break;
-        case NodeOp::ADD: case NodeOp::SUB: v = b[n.a] + b[n.b]; break;
-        case NodeOp::MUL: v = b[n.a] * b[n.b]; break;
-        case NodeOp::NEG: v = b[n.a]; break;
-        case NodeOp::POWI:
-            if (n.ipow < 0) return false;
-            v = std::pow(b[n.a], (double)n.ipow);
+        case NodeOp::CONST: l = h = (double)n.cval; break;
+        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: l = -radius; h = radius; break;
+        case NodeOp::ADD: l = lo[n.a] + lo[n.b]; h = hi[n.a] + hi[n.b]; break;
+        case NodeOp::SUB: l = lo[n.a] - hi[n.b]; h = hi[n.a] - lo[n.b]; break;
+        case NodeOp::NEG: l = -hi[n.a]; h = -lo[n.a]; break;
+        case NodeOp::MUL:
+            if (n.a == n.b) powrange(lo[n.a], hi[n.a], 2, l, h);
+            else mulrange(lo[n.a], hi[n.a], lo[n.b], hi[n.b], l, h);
             break;
         case NodeOp::DIV: {
-            const Node& d = p.nodes[n.b];
-            if (d.op != NodeOp::CONST || d.cval == 0.0f || !std::isfinite(d.cval)) return false;
-            v = b[n.a] / std::fabs((double)d.cval);
+            const double bl = lo[n.b], bh = hi[n.b];
+            if (!(bl > TINY || bh < -TINY)) return false;  // divisor may reach 0
+            mulrange(lo[n.a], hi[n.a], 1.0 / bh, 1.0 / bl, l, h);
+            break;
+        }
+        case NodeOp::POWI: {
+            const int e = n.ipow < 0 ? -n.ipow : n.ipow;
+            double pl, ph;
+            powrange(lo[n.a], hi[n.a], e, pl, ph);
+            if (n.ipow > 0) { l = pl; h = ph; }
+            else {
+                if (!(pl > TINY || ph < -TINY)) return false;
+                l = 1.0 / ph;
+                h = 1.0 / pl;
+            }
             break;
         }
         default: return false;  // general pow
         }
-        if (!(v < LIMIT)) return false;  // also rejects NaN / inf constants
-        b[i] = v * (1.0 + 1e-6) + 1e-30;  // rounding slack
+        if (!(l == l) || !(h == h)) return false;
+        // widen: float roundings of the operands / result, and keep clear of the limits
+        const double w = 1e-5 * std::max(std::fabs(l), std::fabs(h)) + 1e-35;
+        l -= w;
+        h += w;
+        if (!(l > -LIMIT && h < LIMIT)) return false;
+        lo[i] = l;
+        hi[i] = h;
     }
     return true;
 }
@@ -436,16 +475,36 @@ std::string emit_hip_interval(const Program& p) {
         }
         case NodeOp::DIV: {
             const Node& B = p.nodes[n.b];
-            if (B.op != NodeOp::CONST || B.cval == 0.0f) return std::string();
-            if (B.cval > 0.0f) { lo = L(n.a) + " / " + cst(B.cval); hi = H(n.a) + " / " + cst(B.cval); }
-            else { lo = H(n.a) + " / " + cst(B.cval); hi = L(n.a) + " / " + cst(B.cval); }
+            if (B.op == NodeOp::CONST && B.cval != 0.0f) {
+                if (B.cval > 0.0f) { lo = L(n.a) + " / " + cst(B.cval); hi = H(n.a) + " / " + cst(B.cval); }
+                else { lo = H(n.a) + " / " + cst(B.cval); hi = L(n.a) + " / " + cst(B.cval); }
+            } else {
+                // finite_on_domain() proved the divisor keeps one sign (and stays away from 0) on the
+                // whole domain, so the quotient is monotone in each operand: extremes at the corners
+                const std::string t = "d" + std::to_string(i);
+                pre = "    const float " + t + "a = " + L(n.a) + " / " + L(n.b) + ", " + t + "b = " + L(n.a) + " / " + H(n.b) + ", " +
+                      t + "c = " + H(n.a) + " / " + L(n.b) + ", " + t + "d = " + H(n.a) + " / " + H(n.b) + ";\n";
+                lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
+                hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
+            }
             break;
         }
         case NodeOp::POWI: {
-            if (n.ipow < 2) return std::string();
+            if (n.ipow == 0 || n.ipow == 1) return std::string();
             std::snprintf(buf, sizeof buf, "mc_pow_int<%d>", n.ipow);
             const std::string pw = buf;
-            if (n.ipow % 2 == 0) {
+            if (n.ipow < 0) {
+                // base keeps one sign and stays away from 0 (finite_on_domain): x^-n decreases in |x|
+                if ((-n.ipow) % 2 == 0) {
+                    pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
+                          "b = __builtin_fabsf(" + H(n.a) + ");\n";
+                    lo = pw + "(__builtin_fmaxf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
+                    hi = pw + "(__builtin_fminf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
+                } else {
+                    lo = pw + "(" + H(n.a) + ")";
+                    hi = pw + "(" + L(n.a) + ")";
+                }
+            } else if (n.ipow % 2 == 0) {
                 pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
                       "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
                       std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +

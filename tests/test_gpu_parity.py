@@ -265,11 +265,36 @@ def test_sphere_1024_properties(mc, ctx):
     assert counts.mean() > 3
 
 
+RATIONAL = {
+    "div_pos": "x^2+y^2+z^2-1/(x*x+4)",          # divisor bounded away from 0: interval walk
+    "div_lin": "x/(y+3)+z*z-0.1",
+    "negpow": "(x+3)^-2+y^2+z^2-0.2",
+    "negpow_odd": "(y-2.5)^-3+x*x+z",
+    "div_var": "x/(y*y+0.01)+z",                 # large but finite
+    "div_zero": "x/y+z",                         # divisor crosses 0: sampling fallback, inf/nan samples
+}
+
+
+@pytest.mark.parametrize("name", sorted(RATIONAL))
+@pytest.mark.parametrize("n", [24, 300])
+def test_rational_equations(mc, orc, ctx, name, n):
+    """Division and negative powers: bit-exact vs the oracle whichever walk (interval / sampling) is used."""
+    z = (0, -1) if n < 100 else (147, 152)
+    check_against_oracle(mc, orc, ctx, RATIONAL[name], step_of(n), z=z)
+
+
+EQ_ALL = dict(EQ, **RATIONAL)
+
+
 @pytest.mark.parametrize("name,n,iso", [("sphere", 96, 0.0), ("eq3", 96, 0.0), ("eq8", 80, 0.0), ("eq2", 64, 0.0),
-                                        ("eq6", 64, 0.0), ("goursat", 96, -0.4), ("ui_default", 40, 0.0)])
+                                        ("eq6", 64, 0.0), ("goursat", 96, -0.4), ("ui_default", 40, 0.0),
+                                        ("div_pos", 64, 0.0), ("div_lin", 64, 0.0), ("negpow", 64, 0.0),
+                                        ("negpow_odd", 64, 0.0), ("div_var", 64, 0.0)])
 def test_interval_row_culling_is_exact(mc, ctx, name, n, iso, monkeypatch):
-    """K1 proves rows uniform with interval arithmetic (mc_f_iv) and skips sampling them; a build
-    with the culling compiled out (MC_NO_CULL) must give byte-identical codes and vertices."""
+    """K1 proves rows / lanes uniform with interval arithmetic (mc_f_iv) and never samples them; a
+    build with the interval walk compiled out (MC_NO_CULL: the sampling walk) must give
+    byte-identical codes and vertices."""
+    EQ = EQ_ALL
     a = ctx.march(EQ[name], step_of(n), iso)
     ca, va = a.codes(), a.vertices()
     monkeypatch.setenv("MC_JIT_EXTRA", "#define MC_NO_CULL 1")
