@@ -48,7 +48,10 @@ enum {
                                /* without it normals are written as 0                                 */
     MC_FLAG_KEEP_CODES = 2u,   /* keep the per-cell cube codes readable through mc_copy_codes()       */
     MC_FLAG_NO_EMIT = 4u,      /* classify + count only (cube codes and triangle count, no vertices)  */
-    MC_FLAG_TILE1 = 8u         /* diagnostic: classify with row tiles of height 1 (no sample reuse)   */
+    MC_FLAG_TILE1 = 8u,        /* diagnostic: classify with row tiles of height 1 (no sample reuse)   */
+    MC_FLAG_TRI_META = 16u     /* also keep, per triangle, the table row used and its number inside   */
+                               /* the cell (mc_copy_tri_meta); needed to rebuild the reference's      */
+                               /* indexed Poly_Data (marching.cpp:599-654) from the soup              */
 };
 
 typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */
@@ -126,6 +129,9 @@ int mc_march_simple(mc_context *ctx, const char *equation, int grid_res, float i
 int mc_copy_vertices(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_soup(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
+/* mc_copy_tri_meta: n_tris uint16: (table row used, 0..255) | (triangle number inside its cell << 8);
+ * needs MC_FLAG_TRI_META.  A triangle with number 0 starts a new cell (marching.cpp:586-594). */
+int mc_copy_tri_meta(mc_context *ctx, uint16_t *host, uint64_t max_tris);
 
 /* marching.cpp:372-377: trip count of `for (v=-1.0f; v <= (float)(1.0+0.5*step); v += step)`. 0 if step rejected. */
 int mc_cells_per_axis(float step);

@@ -17,19 +17,29 @@
 //   Marching::recalculate() -> bool              full sweep (marching.cpp:368-384) on the GPU
 //   Marching::get_poly_data() -> Poly_Data*      same layout: vertex_list float xyz, tri_list u32
 //
-// Differences, all documented in DESIGN.md: the mesh is triangle SOUP (tri_list = 0..3T-1, the
-// reference's std::set vertex welding, marching.cpp:627-643, is a "next" row); `normal_list`
-// (gradient normals, 3 floats per vertex) is an extra member; step-by-step, seed mode,
-// constraints and PLY dialogs are outside the hot path and not provided; a failed GPU call makes
-// recalculate() return false and last_error() non-empty instead of crashing.
+//   Marching::save_poly_to_file / load_poly_from_file   same ASCII PLY (marching.cpp:665-854), path argument
+//                                                instead of the Win32 dialog
+//
+// Differences, all documented in DESIGN.md: by default the mesh is the triangle SOUP the GPU emits
+// (tri_list = 0..3T-1) with `normal_list` (gradient normals, 3 floats per vertex) as an extra
+// member; set_indexed(true) additionally runs the reference's vertex welding on the host -- the
+// same std::set<xyz> with the same tolerance comparator fed in the same order
+// (marching.cpp:599-643, marching.h:32-55), so vertex_list / tri_list come out as the reference
+// builds them (normal_list is then empty).  Step-by-step, seed mode and constraints are outside
+// the hot path and not provided; a failed GPU call makes recalculate() return false and
+// last_error() non-empty instead of crashing.
 #pragma once
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <exception>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "mc_hip.h"
+#include "mc_tables_data.h"
 
 namespace mc_amd {
 
@@ -99,6 +109,8 @@ public:
     void set_scaling_y(float s) { scale_[1] = s; }
     void set_scaling_z(float s) { scale_[2] = s; }
     void want_normals(bool b) { normals_ = b; }
+    // true: weld vertices like the reference (marching.cpp:599-654); false (default): triangle soup
+    void set_indexed(bool b) { indexed_ = b; }
 
     void reset_all_data() {  // marching.cpp:293-305
         poly_data_.vertex_list.clear();
@@ -118,7 +130,7 @@ public:
         p.scale[0] = scale_[0];
         p.scale[1] = scale_[1];
         p.scale[2] = scale_[2];
-        p.flags = normals_ ? MC_FLAG_NORMALS : 0u;
+        p.flags = (normals_ && !indexed_ ? MC_FLAG_NORMALS : 0u) | (indexed_ ? MC_FLAG_TRI_META : 0u);
         p.z_begin = 0;
         p.z_end = -1;
         mc_result r{};
@@ -133,6 +145,7 @@ public:
             error_ = mc_last_error();
             return false;
         }
+        if (indexed_) return weld_like_reference(inter, r.n_tris);
         poly_data_.vertex_list.resize(nv * 3);
         poly_data_.normal_list.resize(nv * 3);
         poly_data_.tri_list.resize(nv);
@@ -147,11 +160,140 @@ public:
     }
 
     const Poly_Data* get_poly_data() const { return &poly_data_; }  // marching.cpp:656-658
+
+    // marching.cpp:771-854 save_poly_to_file: the same ASCII PLY, byte for byte ("element face N "
+    // carries the reference's trailing blank), to an explicit path instead of a Win32 dialog
+    bool save_poly_to_file(const std::string& path) const {
+        if (poly_data_.vertex_list.empty()) return false;
+        FILE* fp = std::fopen(path.c_str(), "w");
+        if (!fp) return false;
+        const int np = (int)(poly_data_.vertex_list.size() / 3), nt = (int)(poly_data_.tri_list.size() / 3);
+        std::fprintf(fp, "ply\nformat ascii 1.0\n");
+        std::fprintf(fp, "element vertex %d\n", np);
+        std::fprintf(fp, "property float x\nproperty float y\nproperty float z\n");
+        std::fprintf(fp, "element face %d \n", nt);
+        std::fprintf(fp, "property list uchar int vertex_indices\nend_header\n");
+        for (int i = 0; i < np; ++i)
+            std::fprintf(fp, "%f %f %f\n", poly_data_.vertex_list[3 * i], poly_data_.vertex_list[3 * i + 1],
+                         poly_data_.vertex_list[3 * i + 2]);
+        for (int i = 0; i < nt; ++i)
+            std::fprintf(fp, "%u %u %u %u\n", 3u, poly_data_.tri_list[3 * i], poly_data_.tri_list[3 * i + 1],
+                         poly_data_.tri_list[3 * i + 2]);
+        std::fclose(fp);
+        return true;
+    }
+
+    // marching.cpp:665-768 load_poly_from_file: same header rules ("ply", "format ascii 1.0", at most
+    // 10 header lines, "element vertex N", "element face N") and the same append-to-current-data
+    // behaviour (the reference does not clear poly_data first)
+    bool load_poly_from_file(const std::string& path) {
+        FILE* fp = std::fopen(path.c_str(), "r");
+        if (!fp) return false;
+        char line[256];
+        auto getl = [&](std::string& out) {
+            if (!std::fgets(line, sizeof line, fp)) { out.clear(); return false; }
+            out = line;
+            return true;
+        };
+        std::string str;
+        if (!getl(str) || str.find("ply") == std::string::npos) { std::fclose(fp); return false; }
+        if (!getl(str) || str.find("format ascii 1.0") == std::string::npos) { std::fclose(fp); return false; }
+        getl(str);
+        int counter = 2, np = 0, nt = 0;
+        while (str.find("end_header") == std::string::npos) {
+            if (++counter >= 10) { std::fclose(fp); return false; }
+            if (str.find("element vertex") != std::string::npos) np = std::atoi(str.c_str() + 15);
+            if (str.find("element face") != std::string::npos) nt = std::atoi(str.c_str() + 13);
+            if (str.empty()) break;
+            getl(str);
+        }
+        for (int i = 0; i < np; ++i) {
+            float x, y, z;
+            if (std::fscanf(fp, "%f", &x) == EOF || std::fscanf(fp, "%f", &y) == EOF || std::fscanf(fp, "%f", &z) == EOF) {
+                std::fclose(fp);
+                return false;
+            }
+            poly_data_.vertex_list.push_back(x);
+            poly_data_.vertex_list.push_back(y);
+            poly_data_.vertex_list.push_back(z);
+        }
+        for (int i = 0; i < nt; ++i) {
+            unsigned num = 0, a, b, c;
+            if (std::fscanf(fp, "%u %u %u %u", &num, &a, &b, &c) == EOF) return false;
+            if (num != 3) { std::fclose(fp); return false; }
+            poly_data_.tri_list.push_back(a);
+            poly_data_.tri_list.push_back(b);
+            poly_data_.tri_list.push_back(c);
+        }
+        std::fclose(fp);
+        return true;
+    }
     const mc_result& last_result() const { return last_; }
     const std::string& last_error() const { return error_; }
 
 private:
+    // marching.h:32-55: the reference's point type; its operator< treats coordinates closer than 1e-6
+    // as equal, axis by axis (not a strict weak order -- reproduced as is, with the same container)
+    struct xyz {
+        float x, y, z;
+        int idx;
+        static bool close_enough(float a, float b) { return std::fabs(a - b) < 0.000001; }
+        bool operator<(const xyz& r) const {
+            if (!close_enough(x, r.x)) return x < r.x;
+            if (!close_enough(y, r.y)) return y < r.y;
+            if (!close_enough(z, r.z)) return z < r.z;
+            return false;
+        }
+    };
+
+    // marching.cpp:599-654 on the soup: per cell, the crossed-edge vertices are inserted in edge
+    // order 0..11 (the order calculate_step builds intersect_coord, :557-583), then the cell's
+    // triangles are appended with the returned indices.
+    bool weld_like_reference(const std::vector<float>& inter, uint64_t n_tris) {
+        static const uint64_t tri_row[256] = MC_TRI_ROW_INIT;
+        std::vector<uint16_t> meta(n_tris);
+        if (n_tris && mc_copy_tri_meta(ctx_.get(), meta.data(), n_tris) != MC_OK) {
+            error_ = mc_last_error();
+            return false;
+        }
+        std::set<xyz> vertex_set;
+        uint64_t t0 = 0;
+        while (t0 < n_tris) {
+            uint64_t t1 = t0 + 1;
+            while (t1 < n_tris && (meta[t1] >> 8) != 0) ++t1;  // triangles t0..t1-1 belong to one cell
+            const int row = meta[t0] & 0xFF;
+            const float* pos[12] = {nullptr};
+            for (uint64_t t = t0; t < t1; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    const int e = (int)((tri_row[row] >> (4 * (3 * (int)(t - t0) + k))) & 0xF);
+                    pos[e] = &inter[(t * 3 + k) * 6];
+                }
+            int vidx[12];
+            for (int e = 0; e < 12; ++e) {
+                vidx[e] = -1;
+                if (pos[e] && !std::isnan(pos[e][0])) {  // :611-613 NaN x is skipped, index stays -1
+                    const int new_i = (int)(poly_data_.vertex_list.size() / 3);  // :629
+                    const int found = vertex_set.insert(xyz{pos[e][0], pos[e][1], pos[e][2], new_i}).first->idx;
+                    if (found == new_i) {
+                        poly_data_.vertex_list.push_back(pos[e][0]);
+                        poly_data_.vertex_list.push_back(pos[e][1]);
+                        poly_data_.vertex_list.push_back(pos[e][2]);
+                    }
+                    vidx[e] = found;
+                }
+            }
+            for (uint64_t t = t0; t < t1; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    const int e = (int)((tri_row[row] >> (4 * (3 * (int)(t - t0) + k))) & 0xF);
+                    poly_data_.tri_list.push_back((unsigned int)vidx[e]);
+                }
+            t0 = t1;
+        }
+        return true;
+    }
+
     Context& ctx_;
+    bool indexed_ = false;
     Evaluator* evaluator_ = nullptr;   // borrowed, never owned (marching.cpp:140-147)
     float grid_step_size_ = 0.25f;     // marching.cpp:24
     float surface_constant_ = 0.0f;

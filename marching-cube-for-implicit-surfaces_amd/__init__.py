@@ -19,13 +19,13 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libmc_hip.so"
 
 MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NOMEM, MC_ERR_OVERFLOW = range(8)
-FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1 = 1, 2, 4, 8
+FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_TRI_META = 1, 2, 4, 8, 16
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
-    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_cells_per_axis", "mc_graph_build",
+    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_tri_meta", "mc_cells_per_axis", "mc_graph_build",
     "mc_graph_replay",
 ]
 
@@ -85,6 +85,7 @@ def lib():
         L.mc_copy_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_soup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_copy_tri_meta.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_cells_per_axis.argtypes = [C.c_float]
         L.mc_graph_build.argtypes = [C.c_void_p, C.POINTER(McParams)]
         L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
@@ -158,6 +159,13 @@ class Result:
         a = np.empty((self.n_tris, 3, 3), dtype=np.float32)
         if self.n_tris:
             _check(lib().mc_copy_soup(self._ctx._h, a.ctypes.data, self.n_tris))
+        return a
+
+    def tri_meta(self) -> np.ndarray:
+        """(n_tris,) uint16: table row used | triangle number inside its cell << 8 (FLAG_TRI_META)."""
+        a = np.empty(self.n_tris, dtype=np.uint16)
+        if self.n_tris:
+            _check(lib().mc_copy_tri_meta(self._ctx._h, a.ctypes.data, self.n_tris))
         return a
 
     def codes(self) -> np.ndarray:

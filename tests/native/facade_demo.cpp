@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 
 #include "mc_marching.hpp"
@@ -15,6 +16,10 @@ int main(int argc, char** argv) {
     const char* eq = argc > 1 ? argv[1] : "x^2+y^2+z^2-1";
     const int grid_res = argc > 2 ? atoi(argv[2]) : 32;
     const float iso = argc > 3 ? (float)atof(argv[3]) : 0.0f;
+    const bool indexed = argc > 4 && strcmp(argv[4], "indexed") == 0;
+    const float scale = argc > 5 ? (float)atof(argv[5]) : 1.0f;
+    const float step_override = argc > 6 ? (float)atof(argv[6]) : 0.0f;
+    const char* ply = argc > 7 ? argv[7] : nullptr;
     try {
         Context ctx(0);
         Evaluator evaluator;                 // default equation "x+y" (evaluator.cpp:6-8)
@@ -26,8 +31,12 @@ int main(int argc, char** argv) {
         Marching march_maker(ctx);
         march_maker.set_evaluator(&evaluator);
         if (march_maker.set_grid_step_size(0.6f)) return 4;  // outside [0.001, 0.5]
-        march_maker.set_grid_step_size(2.0f / (float)grid_res);
+        march_maker.set_grid_step_size(step_override > 0.0f ? step_override : 2.0f / (float)grid_res);
         march_maker.set_surface_constant(iso);
+        march_maker.set_scaling_x(scale);
+        march_maker.set_scaling_y(scale);
+        march_maker.set_scaling_z(scale);
+        march_maker.set_indexed(indexed);
         if (!march_maker.recalculate()) {
             printf("error: %s\n", march_maker.last_error().c_str());
             return 5;
@@ -41,6 +50,17 @@ int main(int argc, char** argv) {
         }
         printf("cells_per_axis=%d tris=%zu verts=%zu fnv_soup=%016llx f(1,2,3)=%g\n", march_maker.last_result().cells_per_axis,
                pd->tri_list.size() / 3, pd->vertex_list.size() / 3, (unsigned long long)h, evaluator.evaluate(ctx, 1, 2, 3));
+        if (ply) {  // PLY round trip through the reference's on-disk format (marching.cpp:665-854)
+            if (!march_maker.save_poly_to_file(ply)) return 6;
+            const size_t nv = pd->vertex_list.size(), ni = pd->tri_list.size();
+            if (!march_maker.load_poly_from_file(ply)) return 7;   // appends, like the reference
+            const Poly_Data* q = march_maker.get_poly_data();
+            bool same = q->vertex_list.size() == 2 * nv && q->tri_list.size() == 2 * ni;
+            for (size_t i = 0; same && i < ni; ++i) same = q->tri_list[i] == q->tri_list[ni + i];
+            float maxd = 0.0f;
+            for (size_t i = 0; same && i < nv; ++i) maxd = std::fmax(maxd, std::fabs(q->vertex_list[i] - q->vertex_list[nv + i]));
+            printf("ply_roundtrip=%s maxd=%g\n", same ? "ok" : "MISMATCH", maxd);
+        }
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());
         return 1;

@@ -40,3 +40,38 @@ def test_facade_matches_reference_fingerprints(mc, eq, n, iso, tris, fnv):
     r = subprocess.run([str(build_demo(mc)), eq, str(n), str(iso)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"cells_per_axis={n + 1} tris={tris} verts={3 * tris} fnv_soup={fnv}" in r.stdout
+
+
+# indexed vertex / triangle counts of the unmodified reference (std::set welding)
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,iso,scale,step,verts,tris", [
+    ("x+y", 32, 0.0, 1.0, 0.0, 1122, 4290),
+    ("x^2+y^2+z^2-1", 32, 0.0, 1.0, 0.0, 4758, 9548),
+    ("x^2+y^2+z^2-1", 64, 0.0, 1.0, 0.0, 19230, 38492),
+    ("x^2*y^2+x^2*z^2+z^2*y^2+x*y*z", 32, 0.0, 1.0, 0.0, 1188, 4612),
+    ("(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2", 32, 0.0, 1.0, 0.0, 1237, 2436),
+    ("(x^2+y^2-(1/16))^2+(y^2+z^2-(1/16))^2+(z^2+x^2-(1/16))^2-8*(x^2+y^2+z^2-(1/4))^2", 32, 0.0, 1.0, 0.0, 2820, 5632),
+    ("(x^2)^2+(y^2)^2+(z^2)^2-(x^2+y^2+z^2)", 32, -0.4, 1.0, 0.0, 8628, 16912),
+    ("(x^2+y^2-1)^2 + (x^2+z^2-1)^2 + (z^2+y^2-1)^2 - 0.5", 10, 0.0, 1.1, 0.2, 648, 1312),
+    ("(x-0.1)*(y-0.07)-0.001", 4, 0.0, 1.0, 0.0, 72, 100),
+    ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 4, 0.0, 1.0, 0.0, 108, 148),
+])
+def test_facade_indexed_mesh_matches_reference_counts(mc, eq, n, iso, scale, step, verts, tris):
+    """set_indexed(true): the reference's vertex welding (marching.cpp:599-654) replayed on the GPU soup."""
+    r = subprocess.run([str(build_demo(mc)), eq, str(n), str(iso), "indexed", str(scale), str(step)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"tris={tris} verts={verts} " in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_ply_round_trip(mc, tmp_path):
+    """save_poly_to_file / load_poly_from_file use the reference's ASCII PLY (marching.cpp:665-854)."""
+    ply = tmp_path / "mesh.ply"
+    r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "16", "0", "indexed", "1", "0", str(ply)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ply_roundtrip=ok" in r.stdout and float(r.stdout.split("maxd=")[1].split()[0]) < 1e-6
+    head = ply.read_text().splitlines()[:9]
+    assert head[0] == "ply" and head[1] == "format ascii 1.0" and head[2].startswith("element vertex ")
+    assert head[3:6] == ["property float x", "property float y", "property float z"]
+    assert head[6].startswith("element face ") and head[6].endswith(" ")      # the reference's trailing blank
+    assert head[7] == "property list uchar int vertex_indices" and head[8] == "end_header"
