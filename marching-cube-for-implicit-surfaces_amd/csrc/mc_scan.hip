@@ -3,9 +3,11 @@
 // into a code object (hipcc --genco) that is embedded in libmc_hip.so and loaded with
 // hipModuleLoadData, like the hiprtc-specialised kernels of mc_kernels.hip.
 //
-// K2 turns the per-segment counts written by mc_classify into the exclusive offsets that make
-// the emit kernel's output order identical to the reference's sweep order
-// (Source/marching.cpp:375-383: z, then y, then x; then table order inside a cell).
+// K2 turns the per-GROUP sums (group = 64 consecutive segments; mc_classify adds every tile's
+// counts into them with one 64-bit atomic per non-empty segment) into exclusive group offsets.
+// The emit kernel finishes the prefix inside its group with a wavefront scan, so the output
+// order stays the reference's sweep order (Source/marching.cpp:375-383: z, then y, then x; then
+// table order inside a cell) while the scan touches 64x fewer elements than a per-segment one.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -17,9 +19,9 @@ typedef unsigned char u8;
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
 
-// segcnt[i] = triangles | active<<16 per 256-cell segment.  Three small launches turn it into
-// segoff[i] = exclusive {triangle, active} offsets (u32) plus 64-bit totals.
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_reduce(const u32* __restrict__ segcnt, u32 nseg,
+// grpsum[i] = triangles | active cells << 32 per group.  Three small launches turn it into
+// grpoff[i] = exclusive {triangle, active} offsets (u32) plus 64-bit totals.
+extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_reduce(const u64* __restrict__ segcnt, u32 nseg,
                                                              uint2* __restrict__ blocksum) {
     typedef hipcub::BlockReduce<u64, SCAN_BLOCK> Reduce;
     __shared__ typename Reduce::TempStorage tmp;
@@ -27,10 +29,7 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_reduce(const u3
     u64 acc = 0;  // tris in the low half, active cells in the high half
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < nseg) {
-            const u32 v = segcnt[base + i];
-            acc += (u64)(v & 0xFFFFu) | ((u64)(v >> 16) << 32);
-        }
+        if (base + i < nseg) acc += segcnt[base + i];
     const u64 tot = Reduce(tmp).Sum(acc);
     if (threadIdx.x == 0) blocksum[blockIdx.x] = make_uint2((u32)tot, (u32)(tot >> 32));
 }
@@ -60,7 +59,7 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_blocks(const ui
     }
 }
 
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_final(const u32* __restrict__ segcnt, u32 nseg,
+extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_final(const u64* __restrict__ segcnt, u32 nseg,
                                                             const ulonglong2* __restrict__ blockoff,
                                                             uint2* __restrict__ segoff) {
     typedef hipcub::BlockScan<u64, SCAN_BLOCK> Scan;
@@ -71,10 +70,7 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_final(const u32
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         u64 v = 0;
-        if (base + i < nseg) {
-            const u32 c = segcnt[base + i];
-            v = (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32);
-        }
+        if (base + i < nseg) v = segcnt[base + i];
         item[i] = sum;  // exclusive within the thread
         sum += v;
     }
