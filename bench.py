@@ -69,6 +69,75 @@ def cpu_baseline(eq, step, n1, budget_s=15.0):
             "mtris_per_s": round(m.n_tris / dt / 1e6, 5)}
 
 
+def halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world):
+    """The one-slab halo of a sampled-field design, exchanged with RCCL send/recv and compared with
+    what this design does instead (every rank evaluates its own top sample plane): identical bits.
+    Outside the timed region; returns (plane bytes, exchange ms, identical)."""
+    if world == 1:
+        return None
+    ax = (-1 + np.arange(n1 + 1, dtype=np.float64) * 0).astype(np.float32)  # rebuilt below with float adds
+    v = np.float32(-1.0)
+    for i in range(n1 + 1):
+        ax[i] = v
+        v = np.float32(v + np.float32(step))
+    def plane(iz):
+        xx, yy = np.meshgrid(ax, ax, indexing="xy")
+        pts = np.stack([xx.ravel(), yy.ravel(), np.full(xx.size, ax[iz], np.float32)], axis=1)
+        return ctx.eval_points(eq, pts)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine_top = torch.from_numpy(plane(ze)).to(dev)        # sample plane above my last layer = next rank's first plane
+    theirs = torch.empty_like(mine_top)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.irecv, theirs, rank + 1))   # the halo a sampled-field design would need
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(plane(zb)).to(dev), rank - 1))
+    for w in dist.batch_isend_irecv(ops) if ops else []:
+        w.wait()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    same = True if rank + 1 >= world else bool(torch.equal(theirs.view(torch.int32), mine_top.view(torch.int32)))
+    flag = torch.tensor([1 if same else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return {"plane_bytes": int(mine_top.numel() * 4), "exchange_ms_incl_plane_eval": round(ms, 3),
+            "recomputed_plane_identical_to_exchanged": bool(flag.item())}
+
+
+def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
+    """BASELINE config 5: Goursat form, grid_res 512, iso swept -0.7 -> -0.1, graph replay."""
+    if world != 1:
+        raise SystemExit("--mode isosweep is a single-GPU measurement")
+    eq = "(x^2)^2+(y^2)^2+(z^2)^2-(x^2+y^2+z^2)"
+    n = 512 if args.grid_res == 1024 else args.grid_res
+    step = float(np.float32(2.0) / np.float32(n))
+    ctx = mc_amd.Context(local_rank)
+    frames = max(args.steps, 2)
+    isos = np.linspace(-0.7, -0.1, frames).astype(np.float32)
+    ctx.graph_build(eq, step, iso=-0.4)            # -0.4 has the most triangles: sizes the vertex buffer
+    for iso in isos[: args.warmup]:
+        ctx.graph_replay(float(iso))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tris = 0
+    gpu_ms = 0.0
+    for iso in isos:
+        r = ctx.graph_replay(float(iso))
+        tris += r.n_tris
+        gpu_ms += r.ms_total
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n1 = mc_amd.cells_per_axis(step)
+    print(json.dumps({"metric": "Mtris/s", "value": round(tris / dt / 1e6, 2), "unit": "Mtris/s", "n_gpus": 1, "steps": frames,
+                      "warmup": args.warmup, "ms_per_step": round(dt / frames * 1e3, 4), "higher_is_better": True,
+                      "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"iso sweep -0.7..-0.1 on {eq}, grid_res {n} ({n1}^3 cells), hipGraph replay per frame",
+                                 "frames": frames, "triangles_total": int(tris)},
+                      "mvoxels_per_s": round(n1 ** 3 * frames / dt / 1e6, 1), "gpu_ms_per_frame": round(gpu_ms / frames, 4)}), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +147,9 @@ def main():
     ap.add_argument("--equation", default="x^2+y^2+z^2-1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-normals", action="store_true")
+    ap.add_argument("--mode", choices=["sweep", "isosweep"], default="sweep",
+                    help="sweep: the headline metric (default).  isosweep: BASELINE config 5 -- animated iso sweep on the "
+                         "512^3 Goursat surface, one captured hipGraph replayed per frame with a new iso value")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +175,8 @@ def main():
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
 
+    if args.mode == "isosweep":
+        return isosweep(args, torch, mc_amd, world, rank, local_rank, dist)
     eq = args.equation
     step = float(np.float32(2.0) / np.float32(args.grid_res))
     n1 = mc_amd.cells_per_axis(step)
@@ -124,6 +198,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world) if world > 1 else None
     for _ in range(args.warmup):
         one_step()
     fence()
@@ -183,6 +258,8 @@ def main():
                          "frac": round(pipe_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(pipe_bytes),
                          "formula": "2*C + 72*T (SURVEY 8d)"},
         }
+        if halo is not None:
+            out["halo"] = halo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eq, step, n1)
         print(json.dumps(out), flush=True)

@@ -74,3 +74,5 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["triangles"] == 617180 and d["config"]["cells"] == 257 ** 3
     assert d["scaling"] == "strong" and d["value"] > 0
+    # the halo plane a sampled-field design would exchange equals the plane each rank recomputes
+    assert d["halo"]["recomputed_plane_identical_to_exchanged"] is True
