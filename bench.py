@@ -69,7 +69,7 @@ def cpu_baseline(eq, step, n1, budget_s=15.0):
             "mtris_per_s": round(m.n_tris / dt / 1e6, 5)}
 
 
-def halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world):
+def halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world, scale=1.0):
     """The one-slab halo of a sampled-field design, exchanged with RCCL send/recv and compared with
     what this design does instead (every rank evaluates its own top sample plane): identical bits.
     Outside the timed region; returns (plane bytes, exchange ms, identical)."""
@@ -83,7 +83,7 @@ def halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world):
     def plane(iz):
         xx, yy = np.meshgrid(ax, ax, indexing="xy")
         pts = np.stack([xx.ravel(), yy.ravel(), np.full(xx.size, ax[iz], np.float32)], axis=1)
-        return ctx.eval_points(eq, pts)
+        return ctx.eval_points(eq, (np.float32(scale) * pts).astype(np.float32))   # marching.cpp:211 scale * coordinate
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     mine_top = torch.from_numpy(plane(ze)).to(dev)        # sample plane above my last layer = next rank's first plane
     theirs = torch.empty_like(mine_top)
@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid-res", type=int, default=1024)
     ap.add_argument("--equation", default="x^2+y^2+z^2-1")
+    ap.add_argument("--workload", choices=["sphere", "gyroid"], default="sphere",
+                    help="sphere: the headline configuration.  gyroid: BASELINE config 4, sin x cos y + sin y cos z + sin z cos x "
+                         "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1)")
+    ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-normals", action="store_true")
     ap.add_argument("--mode", choices=["sweep", "isosweep"], default="sweep",
@@ -178,6 +182,10 @@ def main():
     if args.mode == "isosweep":
         return isosweep(args, torch, mc_amd, world, rank, local_rank, dist)
     eq = args.equation
+    scale = (args.scale,) * 3
+    if args.workload == "gyroid":
+        mc_amd.set_extensions(mc_amd.EXT_TRIG)
+        eq, scale = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)", (12.566371,) * 3
     step = float(np.float32(2.0) / np.float32(args.grid_res))
     n1 = mc_amd.cells_per_axis(step)
     zb, ze = mc_amd.shard_layers(n1, world, rank)
@@ -187,7 +195,7 @@ def main():
     counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if world > 1 else None
 
     def one_step():
-        r = ctx.march(eq, step, 0.0, flags=flags, z_begin=zb, z_end=ze)
+        r = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
         if world > 1:  # the path's one real exchange: per-rank triangle counts -> global offsets
             mine = torch.tensor([r.n_tris], dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(counts_dev, mine)
@@ -198,7 +206,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world) if world > 1 else None
+    halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world, scale[0]) if world > 1 else None
     for _ in range(args.warmup):
         one_step()
     fence()
@@ -241,8 +249,8 @@ def main():
             "metric": "Mvoxels/s", "value": round(cells / (elapsed / args.steps) / 1e6, 2), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"sphere SDF {eq}, grid_res {args.grid_res} ({n1}^3 cells), iso 0, scale 1, "
-                                   f"normals {'off' if args.no_normals else 'on'}",
+            "config": {"workload": f"{'sphere SDF' if eq == 'x^2+y^2+z^2-1' else args.workload} {eq}, grid_res {args.grid_res} "
+                                   f"({n1}^3 cells), iso 0, scale {scale[0]:g}, normals {'off' if args.no_normals else 'on'}",
                        "cells": int(cells), "triangles": int(tris),
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU"},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),

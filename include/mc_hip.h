@@ -91,6 +91,13 @@ const char *mc_last_error(void);  /* thread-local text of the last failing call 
 int mc_device_count(void);        /* gfx950 devices visible to HIP; 0 when none / no driver   */
 
 /* -- expression layer (Evaluator) ---------------------------------------- */
+/* Grammar extensions, process-wide, default 0 = exactly the reference's grammar (evaluator.cpp:139-237 rejects every
+ * letter but x, y, z).  MC_EXT_TRIG adds `sin(...)` and `cos(...)` (include/mc_trig.h defines their arithmetic; there is
+ * no reference result to match) so that BASELINE.json's gyroid workload can be written.  Affects every
+ * entry point that takes an equation or a constraint.  Returns the previous setting. */
+#define MC_EXT_TRIG 1u
+unsigned mc_set_extensions(unsigned ext);
+
 /* Evaluator::set_equation / tokenize accept-reject only (evaluator.cpp:139-237): 1 accept, 0 reject. */
 int mc_expr_check(const char *equation);
 /* Compile to the evaluation DAG the reference's two-stack walk performs (evaluator.cpp:22-107).
@@ -132,6 +139,15 @@ int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
 /* mc_copy_tri_meta: n_tris uint16: (table row used, 0..255) | (triangle number inside its cell << 8);
  * needs MC_FLAG_TRI_META.  A triangle with number 0 starts a new cell (marching.cpp:586-594). */
 int mc_copy_tri_meta(mc_context *ctx, uint16_t *host, uint64_t max_tris);
+
+/* Constraints: Marching::set_constraint0..2(lhs, op, rhs) (Source/marching.h:105-108, marching.cpp:173-200) and
+ * use_constraint0..2(bool) (marching.h:110-113, marching.cpp:202-207).  i in 0..2; op is one of ">=", "<=", ">", "<";
+ * lhs is checked like an equation.  A constraint takes part in the following sweeps of this context once it is both
+ * set and in use (marching.cpp:258): a cell any of whose 8 corners has `lhs(scale*corner) op rhs` false (NaN counts
+ * as false) is skipped (marching.cpp:476) -- it emits no triangles and its code byte reads 0.  The reference's
+ * set_constraint falls off its end without a return value on success (marching.cpp:199-200); here it is MC_OK. */
+int mc_set_constraint(mc_context *ctx, int i, const char *lhs, const char *op, float rhs);
+int mc_use_constraint(mc_context *ctx, int i, int use);
 
 /* marching.cpp:372-377: trip count of `for (v=-1.0f; v <= (float)(1.0+0.5*step); v += step)`. 0 if step rejected. */
 int mc_cells_per_axis(float step);

@@ -108,6 +108,18 @@ public:
     void set_scaling_x(float s) { scale_[0] = s; }                 // marching.cpp:240-251
     void set_scaling_y(float s) { scale_[1] = s; }
     void set_scaling_z(float s) { scale_[2] = s; }
+    // marching.h:105-113, marching.cpp:173-207.  The constraints live in the GPU context; a cell with a
+    // corner outside an enabled constraint is skipped by recalculate() (marching.cpp:476).
+    bool set_constraint(int i, const std::string& lhs, const std::string& op, float rhs) {
+        return mc_set_constraint(ctx_.get(), i, lhs.c_str(), op.c_str(), rhs) == MC_OK;
+    }
+    bool set_constraint0(const std::string& l, const std::string& o, float r) { return set_constraint(0, l, o, r); }
+    bool set_constraint1(const std::string& l, const std::string& o, float r) { return set_constraint(1, l, o, r); }
+    bool set_constraint2(const std::string& l, const std::string& o, float r) { return set_constraint(2, l, o, r); }
+    bool use_constraint(int i, bool b) { return mc_use_constraint(ctx_.get(), i, b ? 1 : 0) == MC_OK && b; }
+    bool use_constraint0(bool b) { return use_constraint(0, b); }
+    bool use_constraint1(bool b) { return use_constraint(1, b); }
+    bool use_constraint2(bool b) { return use_constraint(2, b); }
     void want_normals(bool b) { normals_ = b; }
     // true: weld vertices like the reference (marching.cpp:599-654); false (default): triangle soup
     void set_indexed(bool b) { indexed_ = b; }

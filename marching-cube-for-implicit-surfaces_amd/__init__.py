@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
     "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_tri_meta", "mc_cells_per_axis", "mc_graph_build",
-    "mc_graph_replay",
+    "mc_graph_replay", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
 ]
 
 
@@ -87,6 +87,8 @@ def lib():
         L.mc_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_tri_meta.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_cells_per_axis.argtypes = [C.c_float]
+        L.mc_set_constraint.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_float]
+        L.mc_use_constraint.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mc_graph_build.argtypes = [C.c_void_p, C.POINTER(McParams)]
         L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
         _lib = L
@@ -99,6 +101,15 @@ def _check(rc):
 
 
 # ---- expression layer (Evaluator) ------------------------------------------------------
+EXT_TRIG = 1
+
+
+def set_extensions(ext: int) -> int:
+    """Process-wide grammar extensions (0 = the reference's grammar; EXT_TRIG adds sin(...) / cos(...))."""
+    lib().mc_set_extensions.restype = C.c_uint
+    return lib().mc_set_extensions(C.c_uint(ext))
+
+
 def expr_check(eq: str) -> bool:
     """Evaluator::set_equation accept/reject (evaluator.cpp:15-17, :139-237)."""
     return bool(lib().mc_expr_check(eq.encode()))
@@ -219,6 +230,15 @@ class Context:
         r = McResult()
         _check(lib().mc_march_simple(self._h, equation.encode(), grid_res, iso, flags, C.byref(r)))
         return Result(self, r)
+
+    def set_constraint(self, i: int, lhs: str, op: str, rhs: float, use: bool = True):
+        """Marching::set_constraint(i, lhs, op, rhs) + use_constraint(i, use) (marching.cpp:173-207): cells with a
+        corner where `lhs op rhs` is false are skipped by the following sweeps of this context."""
+        _check(lib().mc_set_constraint(self._h, i, lhs.encode(), op.encode(), C.c_float(rhs)))
+        _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))
+
+    def use_constraint(self, i: int, use: bool):
+        _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))
 
     def eval_points(self, equation, pts) -> np.ndarray:
         """Evaluator::evaluate for many points (evaluator.cpp:53), computed on the GPU."""

@@ -1,6 +1,8 @@
 // mc_expr.cpp -- see mc_expr.hpp.  Compile with -ffp-contract=off.
 #include "mc_expr.hpp"
 
+#include "mc_trig.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -17,7 +19,7 @@ static bool is_op(char c) { return c == '+' || c == '-' || c == '*' || c == '/' 
 static bool is_num(char c) { return (c >= '0' && c <= '9') || c == '.'; }
 static bool is_var(char c) { return (c >= 'x' && c <= 'z') || (c >= 'X' && c <= 'Z'); }
 
-bool tokenize(const std::string& eq_in, std::vector<Token>& out) {
+bool tokenize(const std::string& eq_in, std::vector<Token>& out, unsigned ext) {
     out.clear();
     if (eq_in.empty()) return false;  // evaluator.cpp:141
     std::string s;
@@ -40,7 +42,17 @@ bool tokenize(const std::string& eq_in, std::vector<Token>& out) {
             out.push_back({TokType::NEG, 'N', 0.0f});
             continue;  // :167 -- `last` deliberately unchanged
         }
-        if (c == '(') {  // :170-178
+        if ((ext & EXT_TRIG) && i + 3 < s.size() && s[i + 3] == '(' &&
+            (((c == 's' || c == 'S') && (s[i + 1] == 'i' || s[i + 1] == 'I') && (s[i + 2] == 'n' || s[i + 2] == 'N')) ||
+             ((c == 'c' || c == 'C') && (s[i + 1] == 'o' || s[i + 1] == 'O') && (s[i + 2] == 's' || s[i + 2] == 'S')))) {
+            // extension E1: a function name fused with its '(' -- placed and counted like a '('
+            if (last == L_VAR || last == L_NUM || last == L_BC) implicit_mul();
+            out.push_back({TokType::FUNC, (c == 's' || c == 'S') ? 's' : 'c', 0.0f});
+            out.push_back({TokType::BRAC_O, '(', 0.0f});
+            ++depth;
+            last = L_BO;
+            i += 3;
+        } else if (c == '(') {  // :170-178
             if (last == L_VAR || last == L_NUM || last == L_BC) implicit_mul();
             out.push_back({TokType::BRAC_O, c, 0.0f});
             ++depth;
@@ -146,6 +158,14 @@ struct Builder {
         n.deps = nodes[a].deps;
         return intern(n);
     }
+    int trig(char f, int a) {  // extension E1
+        if (is_const(a)) return constant(f == 's' ? mc_sinf(nodes[a].cval) : mc_cosf(nodes[a].cval));
+        Node n;
+        n.op = f == 's' ? NodeOp::SIN : NodeOp::COS;
+        n.a = a;
+        n.deps = nodes[a].deps;
+        return intern(n);
+    }
     // value = a op b  (evaluator.cpp:127-136)
     int binary(char op, int a, int b) {
         if (op == '^') {
@@ -233,9 +253,9 @@ bool evaluate_op(Builder& B, SymStacks& S) {
 
 }  // namespace
 
-CompileStatus compile(const std::string& eq, Program& out, std::string& err) {
+CompileStatus compile(const std::string& eq, Program& out, std::string& err, unsigned ext) {
     std::vector<Token> toks;
-    if (!tokenize(eq, toks)) {
+    if (!tokenize(eq, toks, ext)) {
         err = "equation rejected by the tokenizer (Evaluator::set_equation would return false)";
         return CompileStatus::PARSE;
     }
@@ -257,7 +277,14 @@ CompileStatus compile(const std::string& eq, Program& out, std::string& err) {
                 if (!evaluate_op(B, S)) { err = underflow; return CompileStatus::EVAL; }
             }
             S.ops.pop_back();
+            if (!S.ops.empty() && (S.ops.back() == 'S' || S.ops.back() == 'C')) {  // E1: the bracket was a function call
+                const char f = S.ops.back() == 'S' ? 's' : 'c';
+                S.ops.pop_back();
+                if (S.vals.empty()) { err = underflow; return CompileStatus::EVAL; }
+                S.vals.back() = B.trig(f, S.vals.back());
+            }
             break;
+        case TokType::FUNC: S.ops.push_back(t.ch == 's' ? 'S' : 'C'); break;
         case TokType::OP: S.ops.push_back(t.ch); break;
         }
     }
@@ -293,12 +320,12 @@ CompileStatus compile(const std::string& eq, Program& out, std::string& err) {
 }
 
 // ------------------------------------------------------------------ codegen
-std::string emit_hip(const Program& p) {
+std::string emit_hip(const Program& p, const char* fname) {
     std::string s;
     char buf[256];
     s += "// generated from: ";
     for (char c : p.equation) s.push_back((c == '\n' || c == '\r' || c == '\\') ? ' ' : c);
-    s += "\n__device__ __forceinline__ float mc_f(float x, float y, float z) {\n";
+    s += std::string("\n__device__ __forceinline__ float ") + fname + "(float x, float y, float z) {\n";
     s += "    (void)x; (void)y; (void)z;\n";
     auto name = [&](int id) -> std::string {
         const Node& n = p.nodes[id];
@@ -325,6 +352,8 @@ std::string emit_hip(const Program& p) {
         case NodeOp::MUL: rhs = name(n.a) + " * " + name(n.b); break;
         case NodeOp::DIV: rhs = name(n.a) + " / " + name(n.b); break;
         case NodeOp::NEG: rhs = "-" + name(n.a); break;
+        case NodeOp::SIN: rhs = "mc_sinf(" + name(n.a) + ")"; break;
+        case NodeOp::COS: rhs = "mc_cosf(" + name(n.a) + ")"; break;
         case NodeOp::POW: rhs = "mc_pow_general(" + name(n.a) + ", " + name(n.b) + ")"; break;
         case NodeOp::POWI:
             if (n.ipow == 2) rhs = name(n.a) + " * " + name(n.a);
@@ -394,6 +423,12 @@ bool finite_on_domain(const Program& p, double radius) {
             }
             break;
         }
+        case NodeOp::SIN: case NodeOp::COS:
+            // mc_trig.h: finite (and within [-1, 1]) exactly when |argument| < 2^20
+            if (!(lo[n.a] > -1048000.0 && hi[n.a] < 1048000.0)) return false;
+            l = -1.0;
+            h = 1.0;
+            break;
         default: return false;  // general pow
         }
         if (!(l == l) || !(h == h)) return false;
@@ -408,10 +443,10 @@ bool finite_on_domain(const Program& p, double radius) {
     return true;
 }
 
-std::string emit_hip_interval(const Program& p) {
+std::string emit_hip_interval(const Program& p, const char* fname) {
     std::string s;
     char buf[512];
-    s += "__device__ __forceinline__ void mc_f_iv(float xl, float xh, float yl, float yh, float zl, float zh, float& lo, float& hi) {\n";
+    s += std::string("__device__ __forceinline__ void ") + fname + "(float xl, float xh, float yl, float yh, float zl, float zh, float& lo, float& hi) {\n";
     s += "    (void)xl; (void)xh; (void)yl; (void)yh; (void)zl; (void)zh;\n";
     auto L = [&](int id) -> std::string {
         const Node& n = p.nodes[id];
@@ -523,6 +558,11 @@ std::string emit_hip_interval(const Program& p) {
             }
             break;
         }
+        case NodeOp::SIN: case NodeOp::COS:
+            // mc_sin_iv / mc_cos_iv (mc_kernels.hip): endpoints when no extremum can lie inside, else +-1
+            s += "    float " + l + ", " + h + ";\n    " + (n.op == NodeOp::SIN ? "mc_sin_iv(" : "mc_cos_iv(") + L(n.a) + ", " + H(n.a) +
+                 ", " + l + ", " + h + ");\n";
+            continue;
         default: return std::string();  // general pow
         }
         s += pre;
@@ -551,6 +591,8 @@ float eval_host(const Program& p, float x, float y, float z) {
         case NodeOp::NEG: r = -a; break;
         case NodeOp::POW: r = pow_general(a, b); break;
         case NodeOp::POWI: r = pow_literal_int(a, n.ipow); break;
+        case NodeOp::SIN: r = mc_sinf(a); break;
+        case NodeOp::COS: r = mc_cosf(a); break;
         }
         v[i] = r;
     }

@@ -17,18 +17,23 @@
 
 namespace mc {
 
-enum class TokType : uint8_t { OP, NUM, VAR, BRAC_O, BRAC_C, NEG };
+enum class TokType : uint8_t { OP, NUM, VAR, BRAC_O, BRAC_C, NEG, FUNC };
+
+// Grammar extensions (off by default: the reference's tokenizer rejects every letter but x, y, z).
+// EXT_TRIG: `sin(` / `cos(` (any case) open a bracket whose value is passed through mc_sinf /
+// mc_cosf (include/mc_trig.h) when the bracket closes; otherwise they behave like `(`.
+enum : unsigned { EXT_TRIG = 1u };
 
 struct Token {
     TokType type;
-    char ch;    // operator / bracket / variable letter; 'N' for NEG
+    char ch;    // operator / bracket / variable letter; 'N' for NEG; 's' / 'c' for FUNC
     float num;  // NUM: strtof(text) (the reference calls stof per evaluation, evaluator.cpp:82)
 };
 
 // evaluator.cpp:139-237.  true = the reference's tokenize() accepts the string.
-bool tokenize(const std::string& eq, std::vector<Token>& out);
+bool tokenize(const std::string& eq, std::vector<Token>& out, unsigned ext = 0);
 
-enum class NodeOp : uint8_t { CONST, VARX, VARY, VARZ, ADD, SUB, MUL, DIV, POW, POWI, NEG };
+enum class NodeOp : uint8_t { CONST, VARX, VARY, VARZ, ADD, SUB, MUL, DIV, POW, POWI, NEG, SIN, COS };
 
 struct Node {
     NodeOp op;
@@ -49,10 +54,10 @@ struct Program {
 enum class CompileStatus { OK, PARSE, EVAL };
 
 // Symbolic execution of evaluator.cpp:53-107 / :22-48.
-CompileStatus compile(const std::string& eq, Program& out, std::string& err);
+CompileStatus compile(const std::string& eq, Program& out, std::string& err, unsigned ext = 0);
 
 // HIP source of `__device__ __forceinline__ float mc_f(float x, float y, float z)`.
-std::string emit_hip(const Program& p);
+std::string emit_hip(const Program& p, const char* fname = "mc_f");
 
 // HIP source of `mc_f_iv(xl,xh,yl,yh,zl,zh, lo, hi)`: an enclosure [lo,hi] of every value mc_f
 // COMPUTES for points of the box.  Each IEEE round-to-nearest operation is monotone, so interval
@@ -60,7 +65,7 @@ std::string emit_hip(const Program& p);
 // values exactly -- no widening needed.  Only valid for programs that pass finite_on_domain()
 // (no NaN / inf can arise); the classify kernel uses it to prove whole rows of cells uniform
 // without sampling them.  Returns "" when the program uses an operation it cannot bound.
-std::string emit_hip_interval(const Program& p);
+std::string emit_hip_interval(const Program& p, const char* fname = "mc_f_iv");
 
 // Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
 float eval_host(const Program& p, float x, float y, float z);

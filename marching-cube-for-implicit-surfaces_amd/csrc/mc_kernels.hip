@@ -26,11 +26,14 @@
 //                             (64-bit atomic adds by mc_classify; zeroed before every sweep)
 //   grpoff uint2[ngroups+1]   exclusive scan of grpsum: {triangle offset, active-cell offset}
 //   verts  float[T][3][6]     {x,y,z,nx,ny,nz} per vertex, 72 B per triangle, reference order
+#define MC_TRIG_FN __device__ __forceinline__
 #ifndef MC_JIT
 #include <hip/hip_runtime.h>
 #include "../../include/mc_tables_data.h"
+#include "../../include/mc_trig.h"
 #else
 #include "mc_tables_data.h"
+#include "mc_trig.h"
 #endif
 
 typedef unsigned long long u64;
@@ -56,6 +59,30 @@ __device__ __forceinline__ float mc_pow_int(float a) {
 // the kernels evaluate f at dozens of sites
 __device__ __attribute__((noinline)) float mc_pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
 
+// ------------------------------------------------------------------ extension E1: enclosures of sin / cos
+// [lo, hi] contains every value mc_sinf COMPUTES on [l, h].  mc_sinf is within 1 ulp (<= 1.2e-7) of
+// the true sine and never exceeds 1 in magnitude, and the true sine is monotone between extrema
+// (pi/2 + n*pi): if no extremum can lie in [l, h] the computed endpoint values, widened by 3e-7,
+// bound the range; an extremum that may lie inside (tested in double with a guard band) contributes
+// its +-1.  Arguments are finite and below 2^20 here (finite_on_domain, mc_expr.cpp).
+__device__ __forceinline__ void mc_trig_iv(float l, float h, double shift, int which, float& lo, float& hi) {
+    // extrema of sin at (n + 1/2) pi, of cos at n pi: maxima for even n, minima for odd n
+    const double a = (double)l * 0.31830988618379067154 - shift, b = (double)h * 0.31830988618379067154 - shift;
+    const double eps = 1e-9 * (1.0 + __builtin_fabs(a) + __builtin_fabs(b));
+    const double ka = __builtin_ceil(a - eps), kb = __builtin_floor(b + eps);
+    const float vl = mc_trig_eval(l, which), vh = mc_trig_eval(h, which);
+    lo = __builtin_fminf(vl, vh) - 3e-7f;
+    hi = __builtin_fmaxf(vl, vh) + 3e-7f;
+    if (kb >= ka) {
+        const bool two = kb > ka;
+        const bool even = __builtin_fmod(ka, 2.0) == 0.0;
+        if (two || even) hi = 1.0f;
+        if (two || !even) lo = -1.0f;
+    }
+}
+__device__ __forceinline__ void mc_sin_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.5, 0, lo, hi); }
+__device__ __forceinline__ void mc_cos_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.0, 1, lo, hi); }
+
 //@@MC_F_BEGIN  (replaced by generated code when JIT-compiled)
 __device__ __forceinline__ float mc_f(float x, float y, float z) {
     const float t0 = z * z;
@@ -77,6 +104,14 @@ __device__ __forceinline__ void mc_f_iv(float xl, float xh, float yl, float yh, 
     lo = xn * xn + (yn * yn + (zn * zn - 1.0f));
     hi = xm * xm + (ym * ym + (zm * zm - 1.0f));
 }
+#ifdef MC_CHECK_CONS  // stand-alone compile check of the constraint paths: x > -0.5
+#define MC_CONS 1
+__device__ __forceinline__ bool mc_ok(float x, float y, float z) { return x > -0.5f; }
+__device__ __forceinline__ void mc_ok_iv(float xl, float xh, float yl, float yh, float zl, float zh, bool& allok, bool& dead) {
+    allok = xl > -0.5f;
+    dead = !(xh > -0.5f);
+}
+#endif
 //@@MC_F_END
 
 // ------------------------------------------------------------------ parameters
@@ -259,6 +294,9 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
         // everywhere else (marching.cpp:475-479, :497-505)
         const float yl = tl.ys[jj], yu = tl.ys[jj + 1];
         u32 sb = 0;  // bit (4*c + 2*r + pl): sample x0+c, row r (0 lower / 1 upper), plane pl
+#ifdef MC_CONS
+        u32 ob = 0;  // same layout: the sample is inside every enabled constraint (marching.cpp:255-280)
+#endif
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             const float x = tl.xs[ln * 4 + c];
@@ -266,6 +304,12 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
             sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
             sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
             sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
+#ifdef MC_CONS
+            ob |= (mc_ok(x, yl, zk) ? 1u : 0u) << (4 * c + 0);
+            ob |= (mc_ok(x, yl, zk1) ? 1u : 0u) << (4 * c + 1);
+            ob |= (mc_ok(x, yu, zk) ? 1u : 0u) << (4 * c + 2);
+            ob |= (mc_ok(x, yu, zk1) ? 1u : 0u) << (4 * c + 3);
+#endif
         }
         // cube code bit i <-> corner i (marching.cpp:471-472): with s = nibble of sample c and
         // n = nibble of sample c+1:  0:(x0,y0,z0)=s.0  1:(x1,y0,z0)=n.0  2:(x1,y1,z0)=n.2  3:(x0,y1,z0)=s.2
@@ -277,6 +321,10 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
             const u32 code = (sN & 1u) | ((nN & 1u) << 1) | (((nN >> 2) & 1u) << 2) | (((sN >> 2) & 1u) << 3) |
                              (((sN >> 1) & 1u) << 4) | (((nN >> 1) & 1u) << 5) | (((nN >> 3) & 1u) << 6) |
                              (((sN >> 3) & 1u) << 7);
+#ifdef MC_CONS
+            // a cell with a corner outside a constraint is skipped (marching.cpp:476): no triangles, code 0
+            if (((ob >> (4 * c)) & 0xFFu) != 0xFFu) continue;
+#endif
             if (x0 + c < n1) dw |= code << (8 * c);
         }
 
@@ -440,7 +488,13 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     const u64 E0 = __ballot(mc_f(xe, yv, zk) > iso);
     const u64 E1 = __ballot(mc_f(xe, yv, zk1) > iso);
     const u64 ENone = ~((E0 | E1) | ((E0 | E1) >> 1));
+#ifdef MC_CONS
+    // "every sample above iso" proves code 255 only where every sample is also inside the constraints
+    const u64 EOk = __ballot(mc_ok(xe, yv, zk) && mc_ok(xe, yv, zk1));
+    const u64 EFull = (E0 & E1 & EOk) & ((E0 & E1 & EOk) >> 1);
+#else
     const u64 EFull = (E0 & E1) & ((E0 & E1) >> 1);
+#endif
 
     // EXACT row culling.  mc_f_iv bounds every value mc_f can compute on a box (interval arithmetic
     // is exact for round-to-nearest code because each IEEE operation is monotone), so one interval
@@ -455,8 +509,18 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         float lo, hi;
         mc_f_iv(__builtin_fminf(xa, xe), __builtin_fmaxf(xa, xe), __builtin_fminf(yv, yb), __builtin_fmaxf(yv, yb),
                 __builtin_fminf(zk, zk1), __builtin_fmaxf(zk, zk1), lo, hi);
+#ifdef MC_CONS
+        // cells of a box proven wholly outside a constraint are all skipped (code 0, like "none");
+        // "all above iso" is code 255 only if the box is proven wholly inside every constraint
+        bool allok, dead;
+        mc_ok_iv(__builtin_fminf(xa, xe), __builtin_fmaxf(xa, xe), __builtin_fminf(yv, yb), __builtin_fmaxf(yv, yb),
+                 __builtin_fminf(zk, zk1), __builtin_fmaxf(zk, zk1), allok, dead);
+        rowFull = __ballot(lo > iso && allok);
+        rowNone = __ballot(!(hi > iso) || dead);
+#else
         rowFull = __ballot(lo > iso);
         rowNone = __ballot(!(hi > iso));
+#endif
     }
 #endif
     const u64 rowCull = rowNone | rowFull;
@@ -561,8 +625,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
             const float ya = readlane_f(yv, j), yb = readlane_f(yv, j + 1);
             float lo, hi;
             mc_f_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, lo, hi);
+#ifdef MC_CONS
+            bool allok, dead;
+            mc_ok_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, allok, dead);
+            const u64 laneAll = __ballot(lo > iso && allok);
+            const u64 mixedL = __ballot(hi > iso && !dead) & ~laneAll;
+#else
             const u64 laneAll = __ballot(lo > iso);
             const u64 mixedL = __ballot(hi > iso) & ~laneAll;
+#endif
             if (mixedL) {  // the record pass writes this row whole
                 stage(j, mixedL, laneAll);
                 rowbase += p.pitch;
@@ -579,6 +650,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     float r0a[4], r0c[4], r1a[4], r1c[4];
     u64 gtPrev = 0, gePrev = 0;  // lower row, per lane: some sample > iso / every sample > iso
     bool haveLower = false;      // the lower sample row of the next step is in r0a / r0c
+    bool okPrev0 = true;         // MC_CONS: lower row, the lane's first sample column is inside the constraints
 
     // per-lane uniformity of one sample row on the vector unit.  fmax/fmin skip NaN operands, which
     // is right for "some sample > iso" (NaN > iso is false, marching.cpp:498) but not for "every
@@ -592,7 +664,24 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
 #else
 #define MC_ROW_NANFIX(ra, rc, ge)
 #endif
-#define MC_EVAL_ROW(y_, ra, rc, gt, ge)                                                                       \
+#ifdef MC_CONS
+    // constraints in the sampling walk: "every sample above iso" (the proof of code 255) additionally
+    // needs every sample inside the constraints; "no sample above iso" gives code 0 either way.  ok0 =
+    // the lane's first sample column (its left neighbour's x+4 column) is inside, both planes.
+#define MC_ROW_CONS(yy_, ge, ok0)                                                                            \
+    {                                                                                                        \
+        bool a_ = true;                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+            const bool o_ = mc_ok(xs[c], yy_, zk) && mc_ok(xs[c], yy_, zk1);                                 \
+            if (c == 0) ok0 = o_;                                                                            \
+            a_ = a_ && o_;                                                                                   \
+        }                                                                                                    \
+        ge &= __ballot(a_);                                                                                  \
+    }
+#else
+#define MC_ROW_CONS(yy_, ge, ok0)
+#endif
+#define MC_EVAL_ROW(y_, ra, rc, gt, ge, ok0)                                                                     \
     {                                                                                                        \
         const float yy_ = (y_);                                                                              \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
@@ -604,12 +693,14 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         gt = __ballot(mx_ > iso);                                                                            \
         ge = __ballot(mn_ > iso);                                                                            \
         MC_ROW_NANFIX(ra, rc, ge)                                                                            \
+        MC_ROW_CONS(yy_, ge, ok0)                                                                            \
     }
 
     for (int j = 0; j < ny; ++j) {
-        if (!haveLower) MC_EVAL_ROW(readlane_f(yv, j), r0a, r0c, gtPrev, gePrev)
+        if (!haveLower) MC_EVAL_ROW(readlane_f(yv, j), r0a, r0c, gtPrev, gePrev, okPrev0)
         u64 gtNew, geNew;
-        MC_EVAL_ROW(readlane_f(yv, j + 1), r1a, r1c, gtNew, geNew)
+        bool okNew0 = true;
+        MC_EVAL_ROW(readlane_f(yv, j + 1), r1a, r1c, gtNew, geNew, okNew0)
         const u64 anyOwn = gtNew | gtPrev, allOwn = geNew & gePrev;
         const bool none = anyOwn == 0ull && ((ENone >> j) & 1ull);
         const bool full = allOwn == ~0ull && ((EFull >> j) & 1ull);
@@ -624,7 +715,11 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
             u64 topAny = (~ENone >> j) << 63, topAll = (EFull >> j) << 63;
             asm("" : "+s"(topAny), "+s"(topAll));  // keep the halves apart (no 64-bit funnel shift on the SALU)
             const u64 nbAny = ((n0 | n1m | n2 | n3) >> 1) | topAny;
+#ifdef MC_CONS
+            const u64 nbAll = (((n0 & n1m & n2 & n3) & __ballot(okPrev0 && okNew0)) >> 1) | topAll;
+#else
             const u64 nbAll = ((n0 & n1m & n2 & n3) >> 1) | topAll;
+#endif
             const u64 laneAll = allOwn & nbAll;
             const u64 mixedL = (anyOwn | nbAny) & ~laneAll;  // lanes with corners on both sides of iso
             if (mixedL) {  // the record pass writes this row whole
@@ -641,10 +736,12 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         }
         gtPrev = gtNew;
         gePrev = geNew;
+        okPrev0 = okNew0;
         haveLower = true;
     }
 #undef MC_EVAL_ROW
 #undef MC_ROW_NANFIX
+#undef MC_ROW_CONS
 
 #endif  // interval / sampling walk
 

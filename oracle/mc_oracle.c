@@ -6,6 +6,7 @@
  * without -ffast-math: the reference is x86-64 SSE code with one rounding per
  * float operation.
  */
+#include "../include/mc_trig.h"
 #include "mc_oracle.h"
 
 #include <math.h>
@@ -67,6 +68,23 @@ void orc_expr_free(orc_expr *e) {
     }
 }
 
+/* Grammar extension E1 (NOT in the reference, whose tokenizer rejects these letters): `sin(` / `cos(`.
+ * Off unless a test switches it on; the arithmetic is include/mc_trig.h, shared with the product so that the
+ * extension has one definition (there is no reference result for it; tests/test_trig.py checks the accuracy). */
+static unsigned g_ext = 0;
+unsigned orc_set_extensions(unsigned ext) {
+    unsigned old = g_ext;
+    g_ext = ext & 1u;
+    return old;
+}
+static int is_func_at(const char *s, size_t i, size_t n) {
+    if (!(g_ext & 1u) || i + 3 >= n || s[i + 3] != '(') return 0;
+    char a = s[i] | 0x20, b = s[i + 1] | 0x20, c = s[i + 2] | 0x20;
+    if (a == 's' && b == 'i' && c == 'n') return 's';
+    if (a == 'c' && b == 'o' && c == 's') return 'c';
+    return 0;
+}
+
 /* evaluator.cpp:139-237 */
 int orc_tokenize(const char *eq, orc_expr *out) {
     out->n = 0;
@@ -93,6 +111,13 @@ int orc_tokenize(const char *eq, orc_expr *out) {
             neg = 1;
             push_tok(out, ORC_NEG, 'N', 0.0f);
             continue; /* :167 last_tok unchanged */
+        } else if (is_func_at(s, i, n)) { /* E1: placed and counted like a '(' */
+            if (last == ORC_VAR || last == ORC_NUM || last == ORC_BRAC_C) push_tok(out, ORC_OP, '*', 0.0f);
+            push_tok(out, ORC_FUNC, (char)is_func_at(s, i, n), 0.0f);
+            push_tok(out, ORC_BRAC_O, '(', 0.0f);
+            brac++;
+            last = ORC_BRAC_O;
+            i += 3;
         } else if (ch == '(') { /* :170-178 */
             if (last == ORC_VAR || last == ORC_NUM || last == ORC_BRAC_C) push_tok(out, ORC_OP, '*', 0.0f);
             push_tok(out, ORC_BRAC_O, ch, 0.0f);
@@ -257,7 +282,13 @@ static int eval_with(const orc_expr *e, orc_stk *s, float x, float y, float z, f
                 if (evaluate_op(s)) return -1;
             }
             s->opn--;
+            if (s->opn > 0 && (s->ops[s->opn - 1] == 'S' || s->ops[s->opn - 1] == 'C')) { /* E1: apply the function */
+                if (s->vn == 0) return -1;
+                const int which = s->ops[--s->opn] == 'C';
+                s->vals[s->vn - 1].v = mc_trig_eval(s->vals[s->vn - 1].v, which);
+            }
             break;
+        case ORC_FUNC: s->ops[s->opn++] = t->ch == 's' ? 'S' : 'C'; break;
         default: s->ops[s->opn++] = t->ch; break;
         }
     }
@@ -316,11 +347,34 @@ typedef struct {
     const orc_expr *e;
     orc_stk stk;
     float iso, step, sx, sy, sz;
+    int ncons; /* enabled constraints, marching.h:58-69 */
+    const orc_expr *ce[3];
+    orc_stk cstk[3];
+    int cop[3];
+    float crhs[3];
 } orc_ctx;
 
 /* marching.cpp:209-224 Marching::evaluate: f(scale_x*x, scale_y*y, scale_z*z) */
 static int F(orc_ctx *c, float x, float y, float z, float *out) {
     return eval_with(c->e, &c->stk, c->sx * x, c->sy * y, c->sz * z, out);
+}
+
+/* marching.cpp:255-280 check_constraints: every enabled constraint lhs(scaled point) op rhs must hold
+ * (a NaN lhs fails every comparison).  Returns 1 inside, 0 outside, -1 on evaluation underflow. */
+static int within_constraints(orc_ctx *c, float x, float y, float z) {
+    int ok = 1;
+    for (int i = 0; i < c->ncons; i++) {
+        float lhs;
+        if (eval_with(c->ce[i], &c->cstk[i], c->sx * x, c->sy * y, c->sz * z, &lhs)) return -1;
+        const float rhs = c->crhs[i];
+        switch (c->cop[i]) {
+        case ORC_CMP_GE: ok &= lhs >= rhs; break;
+        case ORC_CMP_LE: ok &= lhs <= rhs; break;
+        case ORC_CMP_GT: ok &= lhs > rhs; break;
+        default: ok &= lhs < rhs; break;
+        }
+    }
+    return ok;
 }
 
 /* marching.cpp:437-446 */
@@ -391,8 +445,14 @@ static int cell(orc_ctx *c, orc_layer *L, int want, const float *ax, int ix, int
     const float cy[8] = {y0, y0, y1, y1, y0, y0, y1, y1};
     const float cz[8] = {z0, z0, z0, z0, z1, z1, z1, z1};
     float val[8];
-    for (int i = 0; i < 8; i++) /* :475-479 */
+    for (int i = 0; i < 8; i++) { /* :475-479: the first corner outside a constraint abandons the cell */
+        if (c->ncons) {
+            int w = within_constraints(c, cx[i], cy[i], cz[i]);
+            if (w < 0) return -1;
+            if (!w) { *code_out = 0; return 0; } /* the reference writes nothing for such a cell; its code reads 0 here */
+        }
         if (F(c, cx[i], cy[i], cz[i], &val[i])) return -1;
+    }
     const float iso = c->iso;
     int code = 0; /* :497-505, strict > */
     for (int i = 0; i < 8; i++)
@@ -496,14 +556,30 @@ void orc_mesh_free(orc_mesh *m) {
 
 int orc_march(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want, int z_begin,
               int z_end, int nthreads, orc_mesh *out) {
+    return orc_march_constrained(eq, step, iso, scale, pow_mode, want, z_begin, z_end, nthreads, NULL, 0, out);
+}
+
+int orc_march_constrained(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want,
+                          int z_begin, int z_end, int nthreads, const orc_constraint *cons, int ncons, orc_mesh *out) {
     memset(out, 0, sizeof(*out));
     /* marching.cpp:226-238 set_grid_step_size accepts [0.001, 0.5] (compared in double) */
     if (!((double)step >= 0.001 && (double)step <= .5)) return -3;
+    if (ncons < 0 || ncons > 3) return -1; /* marching.cpp:174 */
     orc_expr e;
-    if (!orc_tokenize(eq, &e)) return -1;
+    orc_expr cexp[3];
+    memset(cexp, 0, sizeof(cexp));
+    for (int i = 0; i < ncons; i++) /* marching.cpp:192-193 */
+        if (cons[i].op < ORC_CMP_GE || cons[i].op > ORC_CMP_LT || !orc_tokenize(cons[i].lhs, &cexp[i])) {
+            for (int k = 0; k < i; k++) orc_expr_free(&cexp[k]);
+            return -1;
+        }
+    if (!orc_tokenize(eq, &e)) {
+        for (int k = 0; k < ncons; k++) orc_expr_free(&cexp[k]);
+        return -1;
+    }
     int n1 = orc_cells_per_axis(step);
     float *ax = (float *)malloc(((size_t)n1 + 1) * sizeof(float));
-    if (!ax) { orc_expr_free(&e); return -4; }
+    if (!ax) { orc_expr_free(&e); for (int k = 0; k < ncons; k++) orc_expr_free(&cexp[k]); return -4; }
     orc_axis_coords(step, ax, n1 + 1);
     if (z_end < 0 || z_end > n1) z_end = n1;
     if (z_begin < 0) z_begin = 0;
@@ -515,10 +591,10 @@ int orc_march(const char *eq, float step, float iso, const float scale[3], int p
     out->n_cells = (uint64_t)plane * (uint64_t)nz;
     if (want & ORC_WANT_CODES) {
         out->codes = (uint8_t *)malloc(out->n_cells ? out->n_cells : 1);
-        if (!out->codes) { free(ax); orc_expr_free(&e); return -4; }
+        if (!out->codes) { free(ax); orc_expr_free(&e); for (int k = 0; k < ncons; k++) orc_expr_free(&cexp[k]); return -4; }
     }
     orc_layer *layers = (orc_layer *)calloc((size_t)(nz > 0 ? nz : 1), sizeof(orc_layer));
-    if (!layers) { free(ax); orc_expr_free(&e); orc_mesh_free(out); return -4; }
+    if (!layers) { free(ax); orc_expr_free(&e); for (int k = 0; k < ncons; k++) orc_expr_free(&cexp[k]); orc_mesh_free(out); return -4; }
     if (nthreads < 1) nthreads = 1;
 
     /* z layers are independent (marching.cpp:375 outer loop); concatenating the
@@ -533,6 +609,13 @@ int orc_march(const char *eq, float step, float iso, const float scale[3], int p
         c.sy = scale[1];
         c.sz = scale[2];
         int bad = stk_init(&c.stk, &e, pow_mode);
+        c.ncons = ncons;
+        for (int i = 0; i < ncons; i++) {
+            c.ce[i] = &cexp[i];
+            c.cop[i] = cons[i].op;
+            c.crhs[i] = cons[i].rhs;
+            bad |= stk_init(&c.cstk[i], &cexp[i], pow_mode);
+        }
         uint8_t *tmp = NULL;
         if (!(want & ORC_WANT_CODES)) tmp = (uint8_t *)malloc(plane ? plane : 1);
 #pragma omp for schedule(dynamic, 1)
@@ -556,6 +639,7 @@ int orc_march(const char *eq, float step, float iso, const float scale[3], int p
         }
         free(tmp);
         stk_free(&c.stk);
+        for (int i = 0; i < ncons; i++) stk_free(&c.cstk[i]);
     }
 
     int err = 0;
@@ -593,6 +677,7 @@ int orc_march(const char *eq, float step, float iso, const float scale[3], int p
     free(layers);
     free(ax);
     orc_expr_free(&e);
+    for (int k = 0; k < ncons; k++) orc_expr_free(&cexp[k]);
     if (err) {
         orc_mesh_free(out);
         return err;

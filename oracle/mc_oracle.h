@@ -38,7 +38,7 @@ enum {
 };
 
 /* token types, evaluator.h:21 */
-enum { ORC_OP = 0, ORC_NUM, ORC_VAR, ORC_BRAC_O, ORC_BRAC_C, ORC_NEG };
+enum { ORC_OP = 0, ORC_NUM, ORC_VAR, ORC_BRAC_O, ORC_BRAC_C, ORC_NEG, ORC_FUNC /* extension E1 only */ };
 
 typedef struct {
     int type;  /* ORC_* */
@@ -51,6 +51,10 @@ typedef struct {
     int cap;
     orc_token *tok;
 } orc_expr;
+
+/* Grammar extension E1 -- sin(...) / cos(...), NOT part of the reference (which rejects them): bit 0 enables it for
+ * every following call; default 0.  Returns the previous value.  Arithmetic: include/mc_trig.h. */
+unsigned orc_set_extensions(unsigned ext);
 
 /* evaluator.cpp:139-237.  Returns 1 (accepted) or 0 (rejected), like the reference. */
 int orc_tokenize(const char *eq, orc_expr *out);
@@ -94,6 +98,18 @@ typedef struct {
 int orc_march(const char *eq, float step, float iso, const float scale[3], int pow_mode,
               int want, int z_begin, int z_end, int nthreads, orc_mesh *out);
 void orc_mesh_free(orc_mesh *m);
+
+/* Constraints (marching.h:58-69, marching.cpp:173-200, :255-280): up to three `lhs op rhs` predicates; a cell
+ * any of whose 8 corners is outside one of them is skipped (marching.cpp:476) -- no triangles, and its code
+ * byte reads 0 here (the reference computes none).  lhs is evaluated at the scaled point like the surface. */
+enum { ORC_CMP_GE = 0, ORC_CMP_LE = 1, ORC_CMP_GT = 2, ORC_CMP_LT = 3 };
+typedef struct {
+    const char *lhs;
+    int op; /* ORC_CMP_* */
+    float rhs;
+} orc_constraint;
+int orc_march_constrained(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want,
+                          int z_begin, int z_end, int nthreads, const orc_constraint *cons, int ncons, orc_mesh *out);
 
 /* FNV-1a 64 (offset 1469598103934665603, prime 1099511628211), SURVEY.md section 4. */
 uint64_t orc_fnv1a(const void *p, size_t n, uint64_t h);

@@ -23,6 +23,10 @@ class _Expr(C.Structure):
     _fields_ = [("n", C.c_int), ("cap", C.c_int), ("tok", C.POINTER(_Token))]
 
 
+class _Constraint(C.Structure):
+    _fields_ = [("lhs", C.c_char_p), ("op", C.c_int), ("rhs", C.c_float)]
+
+
 class _Mesh(C.Structure):
     _fields_ = [
         ("n1", C.c_int),
@@ -67,6 +71,9 @@ def lib():
         L.orc_march.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.POINTER(_Mesh)]
         L.orc_march.restype = C.c_int
+        L.orc_march_constrained.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.POINTER(_Constraint), C.c_int, C.POINTER(_Mesh)]
+        L.orc_march_constrained.restype = C.c_int
         L.orc_mesh_free.argtypes = [C.POINTER(_Mesh)]
         L.orc_fnv1a.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
         L.orc_fnv1a.restype = C.c_uint64
@@ -141,15 +148,29 @@ class Mesh:
     pass
 
 
+def set_extensions(ext: int) -> int:
+    """Grammar extension E1 (sin/cos), not part of the reference; returns the previous setting."""
+    lib().orc_set_extensions.argtypes = [C.c_uint]
+    lib().orc_set_extensions.restype = C.c_uint
+    return lib().orc_set_extensions(ext)
+
+
+CMP = {">=": 0, "<=": 1, ">": 2, "<": 3}  # ORC_CMP_*; the strings marching.cpp:181-190 accepts
+
+
 def march(eq: str, step: float, iso: float = 0.0, scale=(1.0, 1.0, 1.0), pow_mode=POW_LIBM,
-          want=WANT_CODES | WANT_SOUP, z_begin=0, z_end=-1, nthreads=None) -> Mesh:
-    """Run the oracle sweep.  Returns counts, fingerprints and (copied) numpy arrays."""
+          want=WANT_CODES | WANT_SOUP, z_begin=0, z_end=-1, nthreads=None, constraints=()) -> Mesh:
+    """Run the oracle sweep.  Returns counts, fingerprints and (copied) numpy arrays.
+    constraints: up to three (lhs, op, rhs) with op in '>=', '<=', '>', '<' (marching.cpp:173-200)."""
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     m = _Mesh()
     sc = (C.c_float * 3)(*scale)
-    r = lib().orc_march(eq.encode(), C.c_float(step), C.c_float(iso), sc, pow_mode, want, z_begin, z_end, nthreads,
-                        C.byref(m))
+    cons = (_Constraint * max(len(constraints), 1))()
+    for i, (lhs, op, rhs) in enumerate(constraints):
+        cons[i] = _Constraint(lhs.encode(), CMP[op], float(rhs))
+    r = lib().orc_march_constrained(eq.encode(), C.c_float(step), C.c_float(iso), sc, pow_mode, want, z_begin, z_end,
+                                    nthreads, cons, len(constraints), C.byref(m))
     if r:
         raise ValueError(f"orc_march failed ({r}) for {eq!r}")
     out = Mesh()

@@ -37,6 +37,13 @@ int main(int argc, char** argv) {
         march_maker.set_scaling_y(scale);
         march_maker.set_scaling_z(scale);
         march_maker.set_indexed(indexed);
+        if (const char* c = getenv("MC_DEMO_CONSTRAINT")) {  // "lhs op rhs", the developer viewer's `x > -0.5` hotkey
+            char lhs[128], op[8];
+            float rhs;
+            if (sscanf(c, "%127s %7s %f", lhs, op, &rhs) != 3) return 8;
+            if (march_maker.set_constraint0(lhs, "=>", rhs)) return 9;  // not one of the four spellings
+            if (!march_maker.set_constraint0(lhs, op, rhs) || !march_maker.use_constraint0(true)) return 10;
+        }
         if (!march_maker.recalculate()) {
             printf("error: %s\n", march_maker.last_error().c_str());
             return 5;

@@ -75,3 +75,14 @@ def test_facade_ply_round_trip(mc, tmp_path):
     assert head[3:6] == ["property float x", "property float y", "property float z"]
     assert head[6].startswith("element face ") and head[6].endswith(" ")      # the reference's trailing blank
     assert head[7] == "property list uchar int vertex_indices" and head[8] == "end_header"
+
+
+@pytest.mark.gpu
+def test_facade_constraint(mc):
+    """set_constraint0("x", ">", -0.5) + use_constraint0(true), as the reference's developer viewer does;
+    expected count and fingerprint from the oracle (tests/test_oracle_pins.py pins its constraint semantics)."""
+    import os
+    r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "32", "0"], capture_output=True, text=True,
+                       env=dict(os.environ, MC_DEMO_CONSTRAINT="x > -0.5"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tris=6772 " in r.stdout and "fnv_soup=c18a9ae00b655374" in r.stdout, r.stdout

@@ -305,3 +305,64 @@ def test_interval_row_culling_is_exact(mc, ctx, name, n, iso, monkeypatch):
         assert np.array_equal(u32(va), u32(b.vertices()))
     finally:
         plain.close()
+
+
+# ---------------------------------------------------------------- constraints (marching.cpp:173-207, :255-280, :476)
+CONSTRAINT_SETS = {
+    "drawer_x_gt": [("x", ">", -0.5)],                       # the developer viewer's hotkey (marching_test_drawer.h)
+    "slab": [("z", ">=", -0.25), ("z", "<=", 0.25)],
+    "three": [("x", ">", -0.5), ("y+z", "<=", 0.25), ("x*y", ">=", -0.1)],
+    "curved": [("x^2+y^2", "<", 0.49)],
+    "nothing_left": [("x", ">", 5)],
+    "everything": [("x", ">", -5)],
+    "rational": [("1/x", "<", 3)],                           # not boundable: the sampling walk takes it
+}
+
+
+@pytest.mark.parametrize("cname", sorted(CONSTRAINT_SETS))
+@pytest.mark.parametrize("name,n", [("sphere", 40), ("eq3", 64), ("eq8", 300)])
+def test_constraints(mc, orc, name, n, cname):
+    cons = CONSTRAINT_SETS[cname]
+    eq, step = EQ[name], step_of(n)
+    c = mc.Context(0)
+    try:
+        for i, (lhs, op, rhs) in enumerate(cons):
+            c.set_constraint(i, lhs, op, rhs)
+        r = c.march(eq, step)
+        o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=7, constraints=cons)
+        assert np.array_equal(r.codes(), o.codes), "cube codes differ"
+        assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, "positions")
+        # switched off again: the unconstrained surface (use_constraint, marching.cpp:202-207)
+        for i in range(len(cons)):
+            c.use_constraint(i, False)
+        r2 = c.march(eq, step)
+        o2 = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=3)
+        assert r2.n_tris == o2.n_tris and np.array_equal(r2.codes(), o2.codes)
+    finally:
+        c.close()
+
+
+def test_constraints_with_scaling_and_inside_volume(mc, orc):
+    # a solid region (codes 255) cut by a constraint: skipped cells read 0, the rest stay 255
+    c = mc.Context(0)
+    try:
+        c.set_constraint(0, "x+y", ">=", 0.1)
+        eq, step, scale = "1-x^2-y^2-z^2", step_of(48), (1.3, 0.9, 1.1)
+        r = c.march(eq, step, 0.0, scale)
+        o = orc.march(eq, step, 0.0, scale, pow_mode=orc.POW_EXACT, want=7, constraints=[("x+y", ">=", 0.1)])
+        assert np.array_equal(r.codes(), o.codes) and r.n_tris == o.n_tris
+        assert (o.codes == 255).any() and (o.codes == 0).any()
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, "positions")
+    finally:
+        c.close()
+
+
+def test_constraint_errors(mc):
+    c = mc.Context(0)
+    try:
+        for args in [(3, "x", ">", 0.0), (-1, "x", ">", 0.0), (0, "x", "==", 0.0), (0, "x", "=>", 0.0), (0, "x+a", ">", 0.0)]:
+            with pytest.raises(mc.McError):
+                c.set_constraint(*args)
+    finally:
+        c.close()

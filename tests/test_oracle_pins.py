@@ -168,3 +168,35 @@ def test_golden_files_match_oracle(orc):
         assert np.array_equal(m.codes, g["codes"]), f.name
         assert np.array_equal(m.soup.view(np.uint32), g["soup"].view(np.uint32)), f.name
         assert m.fnv_codes == int(g["fnv_codes"]) and m.fnv_soup == int(g["fnv_soup"])
+
+
+# ---------------------------------------------------------------- constraints (marching.cpp:255-280, :476)
+def test_constraints_skip_cells_with_a_corner_outside(orc):
+    step = 2.0 / 32
+    full = orc.march("x^2+y^2+z^2-1", step)
+    cut = orc.march("x^2+y^2+z^2-1", step, constraints=[("x", ">", -0.5)])
+    assert 0 < cut.n_tris < full.n_tris
+    # strict '>': the corner at x = -0.5 itself is outside, so the first surviving cell starts one step later
+    assert cut.soup[:, :, 0].min() >= -0.5 + step - 1e-6
+    n1 = full.n1
+    f, c = full.codes.reshape(n1, n1, n1), cut.codes.reshape(n1, n1, n1)
+    ax = -1 + step * np.arange(n1 + 1)
+    alive = ax[:-1] > -0.5                     # cell ix survives iff its lower corner does (upper is larger)
+    assert np.array_equal(c[:, :, alive], f[:, :, alive]) and not c[:, :, ~alive].any()
+    # >= keeps the corner on the boundary
+    ge = orc.march("x^2+y^2+z^2-1", step, constraints=[("x", ">=", -0.5)])
+    assert ge.n_tris > cut.n_tris
+
+
+def test_constraints_nan_lhs_fails_and_bad_input_is_rejected(orc):
+    step = 0.25
+    # 0/x is NaN at x == 0: every cell touching the x = 0 plane is skipped
+    m = orc.march("x^2+y^2+z^2-1", step, constraints=[("0/x", "<=", 1)])
+    n1 = m.n1
+    c = m.codes.reshape(n1, n1, n1)
+    full = orc.march("x^2+y^2+z^2-1", step).codes.reshape(n1, n1, n1)
+    ax = -1 + step * np.arange(n1 + 1)
+    touches = (ax[:-1] == 0) | (ax[1:] == 0)
+    assert not c[:, :, touches].any() and np.array_equal(c[:, :, ~touches], full[:, :, ~touches])
+    with pytest.raises(ValueError):
+        orc.march("x", step, constraints=[("x+a", ">", 0)])

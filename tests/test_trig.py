@@ -1,0 +1,165 @@
+"""Grammar extension E1: sin(...) / cos(...) (include/mc_trig.h).  NOT a reference feature -- the reference's
+tokenizer rejects these letters (evaluator.cpp:224) -- so parity here is "unpinned by the reference": the tests
+pin (a) default-off behaviour = the reference's, (b) the shared arithmetic against libm to 1 ulp, (c) the
+product (host DAG, device code, interval culling) against the oracle's stack walk on the same grammar."""
+import numpy as np
+import pytest
+
+GYROID = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)"
+f32 = np.float32
+
+
+@pytest.fixture()
+def ext(mc, orc):
+    a, b = mc.set_extensions(mc.EXT_TRIG), orc.set_extensions(1)
+    yield
+    mc.set_extensions(a)
+    orc.set_extensions(b)
+
+
+def test_default_grammar_is_the_references(mc, orc):
+    for eq in ["sin(x)", "cos(y)", "x+sin(z)", "s", "cos"]:
+        assert not mc.expr_check(eq)
+        with pytest.raises(ValueError):
+            orc.march(eq, 0.25)
+
+
+ACCEPT = ["sin(x)", "cos(x)", "2sin(3x)cos(y)", "-sin(x)^2", GYROID, "sin(cos(x+1)*2)", "xsin(y)", "SIN(x)+Cos(y)", "sin(1)",
+          "(x)sin(y)", "sin(-x)", "sin(x)(y)", "x^sin(0)", "sin(x)+"]
+REJECT = ["sin x", "sin()", "sin", "sin(", "si(x)", "sinx", "tan(x)", "sin(x", "sin)x(", "sin(+x)", "s(x)"]
+
+
+def test_tokenizer_with_extension(mc, orc, ext):
+    for eq in ACCEPT:
+        assert mc.expr_check(eq), eq
+    for eq in REJECT:
+        assert not mc.expr_check(eq), eq
+    assert mc.expr_validate("sin(x)+") != 0      # trailing operator: tokenizer accepts, evaluation would underflow
+    # still the reference's quirks: unary minus binds tighter than ^, right-to-left chains
+    assert mc.expr_debug_eval_host("-sin(x)^2", 0.5, 0, 0) > 0
+    # the oracle's tokenizer agrees on every string
+    for eq in ACCEPT + REJECT:
+        try:
+            orc.march(eq, 0.5, want=0)
+            ok = True
+        except ValueError:
+            ok = False
+        assert ok == (mc.expr_validate(eq) == 0), eq
+
+
+def test_host_dag_equals_oracle_walk(mc, orc, ext):
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-7, 7, (300, 3)).astype(f32)
+    for eq in [e for e in ACCEPT if e != "sin(x)+"]:
+        for x, y, z in pts[:60]:
+            a = f32(mc.expr_debug_eval_host(eq, x, y, z))
+            b = f32(orc.evaluate(eq, x, y, z, orc.POW_EXACT))
+            assert a.view(np.uint32) == b.view(np.uint32) or (np.isnan(a) and np.isnan(b)), (eq, x, y, z, a, b)
+
+
+def test_shared_trig_is_within_one_ulp_of_libm(mc, ext):
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.uniform(-4, 4, 4000), rng.uniform(-100, 100, 4000), rng.uniform(-1e4, 1e4, 2000),
+                        rng.uniform(-1e6, 1e6, 2000), [0.0, np.pi / 2, np.pi, -np.pi, 1.5707964]]).astype(f32)
+    for fn, ref in (("sin", np.sin), ("cos", np.cos)):
+        got = np.array([mc.expr_debug_eval_host(f"{fn}(x)", v, 0, 0) for v in x], f32)
+        want = ref(x.astype(np.float64))
+        ulp = np.spacing(np.abs(want).astype(f32)).astype(np.float64)
+        assert np.max(np.abs(got.astype(np.float64) - want) / ulp) <= 1.0
+        assert np.all(np.abs(got) <= 1.0)
+    # outside the defined domain: NaN
+    for v in (1048576.0, -3e6, np.inf, np.nan):
+        assert np.isnan(mc.expr_debug_eval_host("sin(x)", v, 0, 0)) and np.isnan(mc.expr_debug_eval_host("cos(x)", v, 0, 0))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq", [GYROID, "sin(3x)*cos(2y)-z", "sin(x*y)+cos(z/(x^2+1))", "-sin(x)^2+0.3", "sin(x)/cos(y)-z"])
+def test_eval_points_bit_exact(mc, orc, ext, eq):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-9, 9, (20000, 3)).astype(f32)
+    c = mc.Context(0)
+    try:
+        got = c.eval_points(eq, pts)
+    finally:
+        c.close()
+    want = np.array([orc.evaluate(eq, *p, orc.POW_EXACT) for p in pts[:3000]], f32)
+    same = (_u32(got[:3000]) == _u32(want)) | (np.isnan(got[:3000]) & np.isnan(want))
+    assert same.all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,iso,scale", [
+    (GYROID, 48, 0.0, (6.2831853, 6.2831853, 6.2831853)),
+    (GYROID, 200, 0.3, (12.566371, 12.566371, 12.566371)),
+    (GYROID, 33, 0.0, (1.0, 1.0, 1.0)),
+    ("cos(x)+cos(y)+cos(z)", 64, 0.0, (9.424778, 9.424778, 9.424778)),        # Schwarz P
+    ("sin(x)*sin(y)*sin(z)+sin(x)*cos(y)*cos(z)+cos(x)*sin(y)*cos(z)+cos(x)*cos(y)*sin(z)", 40, 0.0, (6.2831853,) * 3),  # diamond
+    ("sin(x)/cos(y)-z", 40, 0.0, (3.0, 3.0, 1.0)),                             # not boundable: sampling walk, inf / NaN cells
+    ("x^2+y^2+z^2-sin(4x)^2", 40, 0.5, (1.0, 1.0, 1.0)),
+])
+def test_sweep_matches_oracle(mc, orc, ext, eq, n, iso, scale):
+    step = float(f32(2.0) / f32(n))
+    c = mc.Context(0)
+    try:
+        r = c.march(eq, step, iso, scale)
+        o = orc.march(eq, step, iso, scale, pow_mode=orc.POW_EXACT, want=7)
+        assert np.array_equal(r.codes(), o.codes)
+        assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active) and o.n_tris > 0
+        v = r.vertices()
+        same = (_u32(v[:, :, :3]) == _u32(o.soup)) | (np.isnan(v[:, :, :3]) & np.isnan(o.soup))
+        assert same.all()
+        d = np.abs(v[:, :, 3:] - o.normals)
+        assert np.nanmax(d) <= 1e-6
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,scale", [(GYROID, 96, 12.566371), ("cos(x)+cos(y)+cos(z)", 80, 9.424778), (GYROID, 64, 1.0)])
+def test_interval_culling_of_trig_is_exact(mc, ext, eq, n, scale, monkeypatch):
+    """mc_sin_iv / mc_cos_iv enclosures cull rows without sampling; compiled out (MC_NO_CULL) the result is identical."""
+    step = float(f32(2.0) / f32(n))
+    a_ctx = mc.Context(0)
+    try:
+        a = a_ctx.march(eq, step, 0.0, (scale,) * 3)
+        ca, va = a.codes(), a.vertices()
+    finally:
+        a_ctx.close()
+    monkeypatch.setenv("MC_JIT_EXTRA", "#define MC_NO_CULL 1")
+    b_ctx = mc.Context(0)
+    try:
+        b = b_ctx.march(eq, step, 0.0, (scale,) * 3)
+        assert np.array_equal(ca, b.codes()) and np.array_equal(_u32(va), _u32(b.vertices()))
+    finally:
+        b_ctx.close()
+
+
+@pytest.mark.gpu
+def test_gyroid_512_slabs_and_properties(mc, ext):
+    """BASELINE config 4's surface at a size the box finishes quickly: z-slabs concatenate to the whole sweep, every
+    vertex lies on a cell edge and on the surface (|f| small)."""
+    n, s = 512, 12.566371
+    step = float(f32(2.0) / f32(n))
+    c = mc.Context(0)
+    try:
+        whole = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS)
+        nt = whole.n_tris
+        assert nt > 5_000_000
+        parts = 0
+        n1 = whole.cells_per_axis
+        for rank in range(4):
+            zb, ze = mc.shard_layers(n1, 4, rank)
+            parts += c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS, zb, ze).n_tris
+        assert parts == nt
+        r = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS)
+        v = r.vertices()[::97].reshape(-1, 6)
+        f = c.eval_points(GYROID, (v[:, :3] * f32(s)).astype(f32))
+        assert np.abs(f).max() < 2e-3          # linear interpolation error on a cell of size 2/512 * 4pi
+        assert np.abs(np.linalg.norm(v[:, 3:], axis=1) - 1).max() < 1e-5
+    finally:
+        c.close()
