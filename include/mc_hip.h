@@ -77,12 +77,16 @@ typedef struct mc_result {
     uint64_t n_active;      /* cells whose cube code is neither 0 nor 255                            */
     uint64_t n_tris;        /* triangles emitted, reference emission order (z, y, x, table order)    */
     const float *d_vertices;/* device: n_tris*3 vertices * 6 floats {x,y,z,nx,ny,nz}; 72 B/triangle  */
-    const uint8_t *d_codes; /* device: raw cube codes, row pitch code_pitch, (z-z_begin, y) rows     */
+    const uint8_t *d_codes; /* device: raw cube codes of cells x < code_main_cells, row pitch         */
+                            /* code_pitch, (z-z_begin, y) rows; mc_copy_codes() gives all n1 per row */
     uint64_t code_pitch;    /* bytes between consecutive (z,y) rows of d_codes                       */
     float ms_classify;      /* GPU time of the classify kernel (hipEvent, ms)                        */
     float ms_scan;          /* ... of the triangle-count scan                                        */
     float ms_emit;          /* ... of the emit kernel                                                */
     float ms_total;         /* first kernel start -> last kernel end                                 */
+    int32_t code_main_cells;/* cells per row held by d_codes (n1, or n1 - (1..4) on 2^k+1 grids)     */
+    const uint32_t *d_codes_tail; /* device, or NULL: one dword per (z,y) row with the codes of cells */
+                            /* code_main_cells..n1-1 (byte k = cell code_main_cells + k)              */
 } mc_result;
 
 /* -- library ------------------------------------------------------------- */

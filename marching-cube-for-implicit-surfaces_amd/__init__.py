@@ -39,7 +39,8 @@ class McResult(C.Structure):
     _fields_ = [("cells_per_axis", C.c_int32), ("z_begin", C.c_int32), ("z_end", C.c_int32),
                 ("n_cells", C.c_uint64), ("n_active", C.c_uint64), ("n_tris", C.c_uint64),
                 ("d_vertices", C.c_void_p), ("d_codes", C.c_void_p), ("code_pitch", C.c_uint64),
-                ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float)]
+                ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
+                ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p)]
 
 
 class McError(RuntimeError):

@@ -25,6 +25,8 @@
 //   grpsum u64[ngroups]       per GROUP of 64 consecutive segments: triangles | active cells << 32
 //                             (64-bit atomic adds by mc_classify; zeroed before every sweep)
 //   grpoff uint2[ngroups+1]   exclusive scan of grpsum: {triangle offset, active-cell offset}
+//   tail   u32[rows]          only when the last chunk is 1..4 cells wide (n1 = 2^k+1): those cells' codes,
+//                             one dword per row, instead of a 128-byte line per row in `codes`
 //   verts  float[T][3][6]     {x,y,z,nx,ny,nz} per vertex, 72 B per triangle, reference order
 #define MC_TRIG_FN __device__ __forceinline__
 #ifndef MC_JIT
@@ -131,10 +133,19 @@ struct McParams {
     float sx, sy, sz;
     float pad;
     u64 cap_tris;       // capacity of the vertex buffer in triangles
+    u32* codes_tail;    // tail plane: one dword per (z,y) row = codes of cells main_cells..n1-1 (when tail_cells)
+    int main_cells;     // cells per row held by the pitched code plane (n1 when there is no tail plane)
+    int tail_cells;     // 0, or 1..4: width of the last chunk when it is handled by tail tiles
+    int nchunk_main;    // chunks swept by the 256-wide tiles (nchunk, or nchunk-1 with a tail plane)
+    int ntile_t;        // tail tiles per layer: ceil(n1/64), one row per lane
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
-#define MC_LIST_CAP 768     // triangles staged per wave in the emit kernel (>= 64 records * 5)
+#ifndef MC_LIST_CAP
+// triangles staged per wave in the emit kernel: one chunk of 64 records holds at most 64 * 5.  The kernel
+// is latency-bound, so LDS is kept small for occupancy (measured: 0.274 ms at 768, 0.269 at 384, 0.256 at 320)
+#define MC_LIST_CAP 320
+#endif
 
 __device__ __constant__ u64 c_tri_row[256] = MC_TRI_ROW_INIT;       // marching_lookup.h:64-320, nibble-packed
 __device__ __constant__ u8 c_tri_count[256] = MC_TRI_COUNT_INIT;
@@ -149,7 +160,12 @@ __device__ __forceinline__ int cz_bit(int v) { return v >> 2; }
 
 // Marching::evaluate (marching.cpp:209-224): f(scale_x*x, scale_y*y, scale_z*z)
 __device__ __forceinline__ float mc_F(const McParams& p, float x, float y, float z) {
+#ifdef MC_UNIT_SCALE  // all three scale factors are exactly 1.0f (the default): 1.0f * x == x bit for bit
+    (void)p;
+    return mc_f(x, y, z);
+#else
     return mc_f(p.sx * x, p.sy * y, p.sz * z);
+#endif
 }
 
 // Wavefront (64-lane) inclusive prefix sum in 7 DPP adds: row_shr 1,2,3 / 4 / 8 inside the
@@ -260,10 +276,13 @@ struct McTileLds {
     float zk, zk1, uz0, uz1;
 };
 
+// TAIL = true: the entries are the tail tile's (row = its lane, chunk lane 0); their code dwords go to
+// tailbuf[row] (LDS) for the tile's one coalesced store instead of into whole code rows.
+template <bool TAIL = false>
 __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCtx& t, const McTileLds& tl,
                                                const unsigned short* s_lut, const unsigned short* ent_pos, u32* seg_cnt,
                                                const u64* row_all, const u64* row_mix, u32 nent,
-                                               u8* __restrict__ codes, u32* __restrict__ recs) {
+                                               u8* __restrict__ codes, u32* __restrict__ recs, u32* tailbuf = nullptr) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int n1 = p.n1;
@@ -377,6 +396,11 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
         // lanes' dwords come from the entry lanes (ds_bpermute), the others are 0 / ~0 by the walk's
         // per-lane masks.  (Writing only the listed dwords here and the rest in the walk made
         // every such line a partial write -- a read-modify-write in HBM; measured.)
+        if (TAIL) {
+            if (valid) tailbuf[j] = dw;
+            e0 += ntake;
+            continue;
+        }
         u64 heads = __ballot(head);
         while (heads) {
             const int h = __builtin_ctzll(heads);
@@ -417,17 +441,29 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     // readfirstlane every tile coordinate (and the whole walk's scalar algebra) lands in VGPRs
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long tile = (long long)blockIdx.x * 4 + w;
-    const long long ntiles = (long long)p.nchunk * p.ntile_y * p.nz;
+    const long long ntiles_main = (long long)p.nchunk_main * p.ntile_y * p.nz;
+    const long long ntiles = ntiles_main + (long long)p.ntile_t * p.nz;
     if (tile >= ntiles) return;  // whole wave
-    const int ch = (int)(tile % p.nchunk);
-    const long long t2 = tile / p.nchunk;
-    const int ty = (int)(t2 % p.ntile_y);
-    const int lz = (int)(t2 / p.ntile_y);
-    const int iz = p.z_begin + lz;
+    const bool is_tail = tile >= ntiles_main;  // wave-uniform
     const int n1 = p.n1;
+    int ch, ty, lz, y0, ny;
+    if (!is_tail) {
+        ch = (int)(tile % p.nchunk_main);
+        const long long t2 = tile / p.nchunk_main;
+        ty = (int)(t2 % p.ntile_y);
+        lz = (int)(t2 / p.ntile_y);
+        y0 = ty * p.tile_h;
+        ny = min(p.tile_h, n1 - y0);
+    } else {  // tail tile: the last chunk's 1..4 cells of 64 consecutive rows, one row per lane
+        const long long tt = tile - ntiles_main;
+        ch = p.nchunk - 1;
+        ty = (int)(tt % p.ntile_t);
+        lz = (int)(tt / p.ntile_t);
+        y0 = ty * 64;
+        ny = min(64, n1 - y0);
+    }
+    const int iz = p.z_begin + lz;
     const int x0 = ch * MC_SEG + lane * 4;
-    const int y0 = ty * p.tile_h;
-    const int ny = min(p.tile_h, n1 - y0);
     const float iso = p.iso;
 
     unsigned short* ent_pos = s_ent_pos[w];
@@ -480,6 +516,62 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
         tl.zk1 = zk1;
         tl.uz0 = p.axis[iz];
         tl.uz1 = p.axis[iz + 1];
+    }
+
+    if (is_tail) {
+        // ---- tail tile: lane = row, cells ch*256 .. n1-1 (1..4 of them) of that row.  One interval
+        // evaluation per lane decides most rows; the others go through the record pass (entry = row,
+        // chunk lane 0), which leaves their code dword in LDS; one coalesced store writes the 64 rows.
+        McTileCtx tt;
+        tt.ch = ch;
+        tt.y0 = y0;
+        tt.iz = iz;
+        tt.lz = lz;
+        tt.lane = lane;
+        tt.seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;
+        const bool rvalid = lane < ny;
+        const u32 vm = p.tail_cells >= 4 ? 0xFFFFFFFFu : ((1u << (8 * p.tail_cells)) - 1u);
+        u64 laneAll = 0ull, mixedL;
+#if defined(MC_HAVE_IV) && defined(MC_FINITE) && !defined(MC_NO_CULL)
+        {
+            const float xa = ax[min(ch * MC_SEG, n1)], xb = ax[min(ch * MC_SEG + 4, n1)];
+            const float yb = ay[min(y0 + lane + 1, n1)];
+            float lo, hi;
+            mc_f_iv(__builtin_fminf(xa, xb), __builtin_fmaxf(xa, xb), __builtin_fminf(yv, yb), __builtin_fmaxf(yv, yb),
+                    __builtin_fminf(zk, zk1), __builtin_fmaxf(zk, zk1), lo, hi);
+#ifdef MC_CONS
+            bool allok, dead;
+            mc_ok_iv(__builtin_fminf(xa, xb), __builtin_fmaxf(xa, xb), __builtin_fminf(yv, yb), __builtin_fmaxf(yv, yb),
+                     __builtin_fminf(zk, zk1), __builtin_fmaxf(zk, zk1), allok, dead);
+            laneAll = __ballot(rvalid && lo > iso && allok);
+            mixedL = __ballot(rvalid && hi > iso && !dead) & ~laneAll;
+#else
+            laneAll = __ballot(rvalid && lo > iso);
+            mixedL = __ballot(rvalid && hi > iso) & ~laneAll;
+#endif
+        }
+#else
+        mixedL = __ballot(rvalid);  // no enclosure for this equation: the record pass evaluates every row
+#endif
+        u32* tailbuf = (u32*)row_all;
+        const u32 cnt = (u32)__builtin_popcountll(mixedL);
+        ent_pos[select_by_mask(mixedL, mask_rank(mixedL), (u32)(MC_ENT_CAP + lane))] = (unsigned short)(lane << 6);
+#ifndef MC_DBG_NO_RECORD
+        if (cnt) mc_record_pass<true>(p, tt, tl, s_lut, ent_pos, seg_cnt, row_all, row_mix, cnt, codes, recs, tailbuf);
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rvalid) {
+            const u32 own = select_by_mask(mixedL, tailbuf[lane], select_by_mask(laneAll, vm, 0u));
+#ifndef MC_DBG_NO_STORE
+            p.codes_tail[(u64)lz * n1 + y0 + lane] = own;
+#endif
+            const u64 sg = tt.seg0 + (u64)lane * p.nchunk;
+            const u32 c = seg_cnt[lane];
+            segcnt[sg] = c;
+            if (c) atomicAdd(&grpsum[sg >> 6], (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32));
+        }
+        return;
     }
 
     // sample column x = xe for the tile's 64 sample rows (lane = row): bit j of E0 / E1 is the
@@ -622,7 +714,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
                 store_codes(((rowFull >> j) & 1ull) ? vmask : 0u);
                 continue;
             }
-            const float ya = readlane_f(yv, j), yb = readlane_f(yv, j + 1);
+            // two undecided rows in a row share ONE lane-level evaluation over the box of both (3 sample
+            // rows): half the interval evaluations, for a few more lanes handed to the record pass
+            // (which is exact, so a lane listed needlessly just yields uniform codes and no record)
+#ifndef MC_NO_PAIR
+            const int pair = (j + 1 < ny && !((rowCull >> (j + 1)) & 1ull)) ? 1 : 0;
+#else
+            const int pair = 0;
+#endif
+            const float ya = readlane_f(yv, j), yb = readlane_f(yv, j + 1 + pair);
             float lo, hi;
             mc_f_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, lo, hi);
 #ifdef MC_CONS
@@ -634,12 +734,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
             const u64 laneAll = __ballot(lo > iso);
             const u64 mixedL = __ballot(hi > iso) & ~laneAll;
 #endif
-            if (mixedL) {  // the record pass writes this row whole
-                stage(j, mixedL, laneAll);
-                rowbase += p.pitch;
-            } else {
-                store_codes(select_by_mask(laneAll, vmask, 0u));
+            for (int r = 0; r <= pair; ++r) {
+                if (mixedL) {  // the record pass writes this row whole
+                    stage(j + r, mixedL, laneAll);
+                    rowbase += p.pitch;
+                } else {
+                    store_codes(select_by_mask(laneAll, vmask, 0u));
+                }
             }
+            j += pair;
         }
     }
 #else
@@ -810,6 +913,20 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
     // coordinates per vertex, and vmcnt retires in order -- a global gather issued after the
     // previous iteration's vertex stores would wait for those stores to land
     extern __shared__ float s_axis[];  // dynamic: n1+1 floats (mc_runtime passes the size)
+    // The kernel is latency-bound (a group holds little work), so every load that does not depend
+    // on another is issued up front: the group's offsets and per-segment counts here, the tables
+    // below, all in flight together; a block none of whose 4 groups has an active cell leaves
+    // before it touches the tables.
+    const McParams p = *P;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
+    const u32 ngroups = (p.nseg + 63u) / 64u;
+    const u32 group = min(blockIdx.x * 4u + (u32)w, ngroups - 1u);  // the grid is rounded up to 4 groups per block
+    const bool in_range = blockIdx.x * 4u + (u32)w < ngroups;
+    const u32 seg_first = group * 64u;
+    const u32 seg = seg_first + (u32)lane;
+    const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
+    const u32 cnt = seg < p.nseg ? segcnt[seg] : 0u;
     {
         // issue every table load before the first wait: a copy loop would pay one full memory
         // latency per iteration (the compiler waits for each load before its LDS store)
@@ -831,21 +948,12 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
         s_row[threadIdx.x] = trow;
         if (threadIdx.x < 12) s_edge[threadIdx.x] = tedge;
     }
-    __syncthreads();
-
-    const McParams p = *P;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
-    // normally one group per wave; the loop only strides when the host caps the grid (A/B hook)
-    const u32 ngroups = (p.nseg + 63u) / 64u;
-    for (u32 group = blockIdx.x * 4u + (u32)w; group < ngroups; group += gridDim.x * 4u) {
-    const u32 seg_first = group * 64u;
-    const u32 seg = seg_first + (u32)lane;
+    const bool mine = in_range && g0.y != g1.y;  // this wave's 64 segments hold an active cell
+    if (!__syncthreads_or(mine ? 1 : 0)) return;  // also the barrier that publishes the tables
+    if (!mine) return;
+    {
     // the scan gives the group's first triangle; the prefix inside the group is a wavefront scan of
     // the per-segment counts (triangles | active cells << 16)
-    const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
-    if (g0.y == g1.y) continue;  // no active cell in these 64 segments
-    const u32 cnt = seg < p.nseg ? segcnt[seg] : 0u;
     const u32 ctri = cnt & 0xFFFFu, cact = cnt >> 16;
     const u32 itri = wave_inclusive_scan(ctri), iact = wave_inclusive_scan(cact);
     const uint2 o0 = make_uint2(g0.x + (itri - ctri), iact - cact);  // {first triangle, group-local first record}
@@ -904,8 +1012,16 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
                     const float gx = mc_F(p, q.x + h, q.y, q.z) - mc_F(p, q.x - h, q.y, q.z);
                     const float gy = mc_F(p, q.x, q.y + h, q.z) - mc_F(p, q.x, q.y - h, q.z);
                     const float gz = mc_F(p, q.x, q.y, q.z + h) - mc_F(p, q.x, q.y, q.z - h);
-                    const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
-                    if (len > 0.0f && !__builtin_isinf(len)) {
+                    const float len2 = (gx * gx + gy * gy) + gz * gz;
+                    const float len = __builtin_sqrtf(len2);
+                    if (len2 >= 1e-30f && !__builtin_isinf(len2)) {
+                        // v_rsq_f32 (1 ulp) instead of an IEEE sqrt and an IEEE divide: the normal is a
+                        // tolerance quantity, and this kernel is VALU-bound
+                        const float inv = __builtin_amdgcn_rsqf(len2);
+                        nx = gx * inv;
+                        ny = gy * inv;
+                        nz = gz * inv;
+                    } else if (len > 0.0f && !__builtin_isinf(len)) {  // tiny gradient: rsq would flush it
                         const float inv = 1.0f / len;
                         nx = gx * inv;
                         ny = gy * inv;
@@ -982,7 +1098,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
         nlist += chunk_t;
     }
     if (nlist) flush();
-    }  // group loop
+    }
 }
 
 // =============================================================== evaluate points

@@ -95,14 +95,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __re
     }
 }
 
-// pitched codes -> compact rows of n1 bytes
-extern "C" __global__ __launch_bounds__(256) void mc_pack_codes(const u8* __restrict__ codes, u64 pitch, int n1, u64 nrows,
-                                                     u8* __restrict__ out) {
+// pitched main plane (+ the tail plane: one dword per row holding cells main_cells..n1-1) -> compact rows of n1 bytes
+extern "C" __global__ __launch_bounds__(256) void mc_pack_codes(const u8* __restrict__ codes, const u32* __restrict__ tail,
+                                                     u64 pitch, int n1, int main_cells, u64 nrows, u8* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
     const u64 total = nrows * (u64)n1;
     if (i < total) {
         const u64 r = i / (u64)n1;
-        out[i] = codes[r * pitch + (i - r * (u64)n1)];
+        const int x = (int)(i - r * (u64)n1);
+        out[i] = x < main_cells ? codes[r * pitch + (u64)x] : (u8)(tail[r] >> (8 * (x - main_cells)));
     }
 }
 
