@@ -141,6 +141,14 @@ struct McParams {
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
+// waves per workgroup.  A workgroup's slot is held until its slowest wave is done, and tiles / groups differ a
+// lot in work, so small workgroups keep more waves resident (mc_runtime passes the same numbers to the launch).
+#ifndef MC_WPB_C
+#define MC_WPB_C 4
+#endif
+#ifndef MC_WPB_E
+#define MC_WPB_E 4
+#endif
 #ifndef MC_LIST_CAP
 // triangles staged per wave in the emit kernel: one chunk of 64 records holds at most 64 * 5.  The kernel
 // is latency-bound, so LDS is kept small for occupancy (measured: 0.274 ms at 768, 0.269 at 384, 0.256 at 320)
@@ -254,7 +262,12 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY 
 //    lookup, ambiguity test, per-segment prefix sums and the compact per-cell RECORDS the
 //    emit kernel consumes -- runs lane-parallel over that list once per tile (a tile has ~35
 //    listed lanes on a smooth surface) instead of wave-wide in each of its ~20 mixed steps.
+#ifndef MC_ENT_CAP
 #define MC_ENT_CAP 512  // (row, lane) positions staged per wave before the record pass runs
+#endif
+#ifndef MC_CLASSIFY_MINW
+#define MC_CLASSIFY_MINW 1
+#endif
 
 struct McTileCtx {
     int ch, y0, iz, lz, lane;
@@ -424,15 +437,17 @@ __device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCt
     __builtin_amdgcn_wave_barrier();
 }
 
-extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
-                                                               u32* __restrict__ segcnt, u32* __restrict__ recs,
-                                                               u64* __restrict__ grpsum) {
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
+                                                                         u32* __restrict__ segcnt, u32* __restrict__ recs,
+                                                                         u64* __restrict__ grpsum) {
     __shared__ unsigned short s_lut[256];  // triangle count | ambiguity face << 8
-    __shared__ unsigned short s_ent_pos[4][MC_ENT_CAP + 64];  // + one dump slot per lane
-    __shared__ u32 s_segcnt[4][64];
-    __shared__ float s_tab[4][2 * 264 + 2 * 72];  // per wave: xs[264] ux[264] ys[72] uy[72] (table slices)
-    __shared__ u64 s_rowall[4][64], s_rowmix[4][64];  // per tile row: lanes all-above / lanes listed
-    s_lut[threadIdx.x] = (unsigned short)(c_tri_count[threadIdx.x] | (c_amb_face[threadIdx.x] << 8));
+    __shared__ unsigned short s_ent_pos[MC_WPB_C][MC_ENT_CAP + 64];  // + one dump slot per lane
+    __shared__ u32 s_segcnt[MC_WPB_C][64];
+    __shared__ float s_tab[MC_WPB_C][2 * 264 + 2 * 72];  // per wave: xs[264] ux[264] ys[72] uy[72] (table slices)
+    __shared__ u64 s_rowall[MC_WPB_C][64], s_rowmix[MC_WPB_C][64];  // per tile row: lanes all-above / lanes listed
+#pragma unroll
+    for (int i = (int)threadIdx.x; i < 256; i += 64 * MC_WPB_C)
+        s_lut[i] = (unsigned short)(c_tri_count[i] | (c_amb_face[i] << 8));
     __syncthreads();
 
     const McParams p = *P;
@@ -440,13 +455,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_classify(const McParams* __
     // the wave index is wave-uniform, but the compiler only knows that if told: without the
     // readfirstlane every tile coordinate (and the whole walk's scalar algebra) lands in VGPRs
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long tile = (long long)blockIdx.x * 4 + w;
+    const long long tile = (long long)blockIdx.x * MC_WPB_C + w;
     const long long ntiles_main = (long long)p.nchunk_main * p.ntile_y * p.nz;
     const long long ntiles = ntiles_main + (long long)p.ntile_t * p.nz;
     if (tile >= ntiles) return;  // whole wave
     const bool is_tail = tile >= ntiles_main;  // wave-uniform
     const int n1 = p.n1;
     int ch, ty, lz, y0, ny;
+    // (chunk fastest: the 4 waves of a workgroup cover 1 KB of each code row together.  Layer-fastest, which
+    // gives the 4 waves equal work, measured the same: 0.380 vs 0.378 ms.)
     if (!is_tail) {
         ch = (int)(tile % p.nchunk_main);
         const long long t2 = tile / p.nchunk_main;
@@ -900,15 +917,15 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
 // Phase 2, one lane per output VERTEX: edge lookup (nibble-packed table row in LDS), two corner
 // evaluations, the interpolation, the central-difference gradient of f for the normal, 24-byte
 // store.
-extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
-                                                           const u32* __restrict__ segcnt, const uint2* __restrict__ grpoff,
-                                                           float* __restrict__ verts, unsigned short* __restrict__ trimeta) {
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                     const u32* __restrict__ segcnt, const uint2* __restrict__ grpoff,
+                                                                     float* __restrict__ verts, unsigned short* __restrict__ trimeta) {
     __shared__ u64 s_row[256];
     __shared__ u8 s_edge[16];
-    __shared__ u32 s_list[4][MC_LIST_CAP];
-    __shared__ u32 s_seg[4][64];
-    __shared__ u32 s_act[4][66];
-    __shared__ u32 s_tri[4][64];
+    __shared__ u32 s_list[MC_WPB_E][MC_LIST_CAP];
+    __shared__ u32 s_seg[MC_WPB_E][64];
+    __shared__ u32 s_act[MC_WPB_E][66];
+    __shared__ u32 s_tri[MC_WPB_E][64];
     // the whole lattice coordinate table (n1+1 <= 2002 floats): the vertex phase gathers 6
     // coordinates per vertex, and vmcnt retires in order -- a global gather issued after the
     // previous iteration's vertex stores would wait for those stores to land
@@ -921,8 +938,8 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
     const u32 ngroups = (p.nseg + 63u) / 64u;
-    const u32 group = min(blockIdx.x * 4u + (u32)w, ngroups - 1u);  // the grid is rounded up to 4 groups per block
-    const bool in_range = blockIdx.x * 4u + (u32)w < ngroups;
+    const u32 group = min(blockIdx.x * (u32)MC_WPB_E + (u32)w, ngroups - 1u);  // the grid is rounded up to whole blocks
+    const bool in_range = blockIdx.x * (u32)MC_WPB_E + (u32)w < ngroups;
     const u32 seg_first = group * 64u;
     const u32 seg = seg_first + (u32)lane;
     const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
@@ -930,22 +947,25 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
     {
         // issue every table load before the first wait: a copy loop would pay one full memory
         // latency per iteration (the compiler waits for each load before its LDS store)
-        const float* __restrict__ gaxis = P->axis;
+        // (the axis buffer is padded to 2052 floats by mc_runtime, so the 16-byte loads need no clamp)
+        constexpr int NT = 64 * MC_WPB_E, NV = (512 + NT - 1) / NT, NR = (256 + NT - 1) / NT;
+        const float4* __restrict__ gaxis = (const float4*)P->axis;
         const int n1p = P->n1;
-        float t[8];
+        float4 t[NV];
+        u64 trow[NR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = (int)threadIdx.x + 256 * k;
-            t[k] = gaxis[min(i, n1p)];
-        }
-        const u64 trow = c_tri_row[threadIdx.x];
+        for (int k = 0; k < NV; ++k) t[k] = gaxis[min((int)threadIdx.x + NT * k, 511)];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) trow[k] = c_tri_row[((int)threadIdx.x + NT * k) & 255];
         const u8 tedge = c_edge_corner[threadIdx.x < 12 ? threadIdx.x : 0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = (int)threadIdx.x + 256 * k;
-            if (i <= n1p) s_axis[i] = t[k];
+        for (int k = 0; k < NV; ++k) {
+            const int i = (int)threadIdx.x + NT * k;
+            if (i < 512 && 4 * i <= n1p) ((float4*)s_axis)[i] = t[k];
         }
-        s_row[threadIdx.x] = trow;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if ((int)threadIdx.x + NT * k < 256) s_row[(int)threadIdx.x + NT * k] = trow[k];
         if (threadIdx.x < 12) s_edge[threadIdx.x] = tedge;
     }
     const bool mine = in_range && g0.y != g1.y;  // this wave's 64 segments hold an active cell
@@ -1053,10 +1073,21 @@ extern "C" __global__ __launch_bounds__(256) void mc_emit(const McParams* __rest
 #endif
                     // three 8-byte stores per vertex.  (Staging the iteration's 1536 contiguous bytes
                     // in LDS and writing 16-byte pieces was measured slower: 0.31 vs 0.29 ms.)
-                    float2* o = (float2*)(verts + (gtri * 3ull + (u64)k) * 6ull);
-                    o[0] = make_float2(q.x, q.y);
-                    o[1] = make_float2(q.z, nx);
-                    o[2] = make_float2(ny, nz);
+                    float* o = verts + (gtri * 3ull + (u64)k) * 6ull;
+#ifdef MC_EMIT_STORE_X4
+                    typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+                    typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
+                    f4u a;
+                    a.x = q.x; a.y = q.y; a.z = q.z; a.w = nx;
+                    f2u b;
+                    b.x = ny; b.y = nz;
+                    *(f4u*)o = a;
+                    *(f2u*)(o + 4) = b;
+#else
+                    ((float2*)o)[0] = make_float2(q.x, q.y);
+                    ((float2*)o)[1] = make_float2(q.z, nx);
+                    ((float2*)o)[2] = make_float2(ny, nz);
+#endif
                     // optional (MC_FLAG_TRI_META): table row actually used | triangle number inside its
                     // cell << 8, so a host can rebuild the reference's per-cell, per-edge vertex order
                     if (want_meta && k == 0) trimeta[gtri] = (unsigned short)(row | (t << 8));
