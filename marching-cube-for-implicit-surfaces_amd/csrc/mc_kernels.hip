@@ -17,11 +17,14 @@
 //   axis   float[n1+1]        lattice coordinate c[i] (c[0]=-1, c[i+1]=c[i]+step, float adds)
 //   axs    float[3][n1+1]     scale_x*c[i], scale_y*c[i], scale_z*c[i] (marching.cpp:211)
 //   codes  u8, pitched        raw cube code per cell; row = (z-z_begin)*n1 + y, pitch % 128 == 0
-//   segcnt u32[nseg]          per SEGMENT (= 256 x-consecutive cells of one row):
-//                             triangles | active cells << 16; seg = row*nchunk + chunk
-//   recs   u32[nseg][256]     per segment, its ACTIVE cells compacted in x order (only the first
-//                             `active` entries are ever written / read): cell | code<<8 | flip<<16 |
-//                             triangles<<17 | triangle prefix inside the segment<<20
+//   segcb  uint2[nseg]        per SEGMENT (= 256 x-consecutive cells of one row; seg = row*nchunk + chunk):
+//                             {triangles | active cells << 16, index of its first record in recs}
+//   recs   u32[cap_recs]      one RECORD per active cell: cell | code<<8 | flip<<16 | triangles<<17 |
+//                             triangle prefix inside the segment<<20.  DENSE: a tile collects its records in
+//                             LDS and appends them with one atomic bump of rec_cursor, so a segment's records
+//                             are contiguous and the whole buffer is 4 B per active cell.  (A 1 KB slot per
+//                             segment -- 5 GB of address space at 1025^3, touched 12 bytes at a time -- cost
+//                             0.10 ms in mc_classify alone: measured by confining the writes to a window.)
 //   grpsum u64[ngroups]       per GROUP of 64 consecutive segments: triangles | active cells << 32
 //                             (64-bit atomic adds by mc_classify; zeroed before every sweep)
 //   grpoff uint2[ngroups+1]   exclusive scan of grpsum: {triangle offset, active-cell offset}
@@ -138,9 +141,16 @@ struct McParams {
     int tail_cells;     // 0, or 1..4: width of the last chunk when it is handled by tail tiles
     int nchunk_main;    // chunks swept by the 256-wide tiles (nchunk, or nchunk-1 with a tail plane)
     int ntile_t;        // tail tiles per layer: ceil(n1/64), one row per lane
+    u32* rec_cursor;    // record allocator, zeroed before every sweep: word 0 = "a region overflowed", then
+                        // MC_NCUR bump cursors 128 bytes apart (word 32*(1+k)), one per region of recs
+    u64 cap_recs;       // capacity of the record buffer in records (MC_NCUR equal regions)
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
+#define MC_REC_CAP 512      // records a wave buffers in LDS before appending them to the global array
+// The record array is split into MC_NCUR regions, each with its own bump cursor; tile t appends to region
+// t % MC_NCUR.  One cursor for the whole sweep serialised 87 k atomics on one address (measured: +0.08 ms).
+#define MC_NCUR 256
 // waves per workgroup.  A workgroup's slot is held until its slowest wave is done, and tiles / groups differ a
 // lot in work, so small workgroups keep more waves resident (mc_runtime passes the same numbers to the launch).
 #ifndef MC_WPB_C
@@ -227,7 +237,14 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 // LDS copy of the tile's slice); element [1] is the upper corner.
 template <typename PX, typename PY, typename PZ>
 __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY uy, PZ uz) {
-    const u32 fc = c_face_corner[face];
+    // the 6 x 16-bit face-corner table lives in two 64-bit immediates, not in memory: a global load here
+    // (even one lane's) would make the wave wait for every code store it still has in flight -- vmcnt
+    // retires in order -- and that serialised the whole back-end behind the walk's stores (measured:
+    // compute 0.19 ms + stores 0.19 ms = 0.38 ms instead of the larger of the two)
+    constexpr unsigned short kfc[6] = MC_FACE_CORNER_INIT;
+    constexpr u64 kfc_lo = (u64)kfc[0] | ((u64)kfc[1] << 16) | ((u64)kfc[2] << 32) | ((u64)kfc[3] << 48);
+    constexpr u64 kfc_hi = (u64)kfc[4] | ((u64)kfc[5] << 16);
+    const u32 fc = (u32)((face < 4 ? kfc_lo >> (16 * face) : kfc_hi >> (16 * (face - 4))) & 0xFFFFull);
     float mx = 0.0f, my = 0.0f, mz = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -262,25 +279,17 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY 
 //    lookup, ambiguity test, per-segment prefix sums and the compact per-cell RECORDS the
 //    emit kernel consumes -- runs lane-parallel over that list once per tile (a tile has ~35
 //    listed lanes on a smooth surface) instead of wave-wide in each of its ~20 mixed steps.
-#ifndef MC_ENT_CAP
-#define MC_ENT_CAP 512  // (row, lane) positions staged per wave before the record pass runs
-#endif
 #ifndef MC_CLASSIFY_MINW
 #define MC_CLASSIFY_MINW 1
 #endif
 
 struct McTileCtx {
     int ch, y0, iz, lz, lane;
+    u32 region;  // this tile's region of the record array
     u64 seg0;  // segment index of tile row 0; + nchunk per row
 };
 
-// lane-parallel pass over the staged positions (sorted by (row, lane)): one lane = one dword
-// of 4 cells whose corners are not all on one side of iso
-//
-// It issues NO vector-memory load: the coordinates it needs come from LDS copies of the tile's
-// table slices (tc) made before the walk's first store.  vmcnt retires in order, so a load
-// issued here would have to wait for every code store the wave still has in flight -- measured,
-// that serialised the walk's compute behind its own stores (0.19 + 0.23 ms instead of the max).
+// LDS copies of the tile's coordinate-table slices for the back-end (see mc_backend)
 struct McTileLds {
     const float* xs;   // [261] scaled x of samples X0 .. X0+256 (clamped to n1), then padding
     const float* ux;   // [261] unscaled
@@ -289,162 +298,251 @@ struct McTileLds {
     float zk, zk1, uz0, uz1;
 };
 
-// TAIL = true: the entries are the tail tile's (row = its lane, chunk lane 0); their code dwords go to
-// tailbuf[row] (LDS) for the tile's one coalesced store instead of into whole code rows.
+// Row state the walk leaves behind for the back-end, lane j = tile row j (v_writelane by the walk):
+// the lanes of row j whose 4 cells are listed (mix) and those proven all-above iso (all).
+struct McRowMasks {
+    u32 mixlo, mixhi, alllo, allhi;
+};
+
+// index of the k-th (0-based) set bit of hi:lo; k < popcount
+__device__ __forceinline__ int nth_set_bit64(u32 lo, u32 hi, u32 k) {
+    u32 c = (u32)__builtin_popcount(lo);
+    const bool up = k >= c;
+    u32 m = up ? hi : lo;
+    k = up ? k - c : k;
+    int base = up ? 32 : 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        c = (u32)__builtin_popcount(m & ((1u << w) - 1u));
+        const bool u = k >= c;
+        m = u ? (m >> w) : m;
+        k = u ? k - c : k;
+        base += u ? w : 0;
+    }
+    return base;
+}
+
+// Back-end of a tile, lane-parallel over its listed dwords ("entries", ordered by (row, lane)): exact
+// evaluation of the entry's 20 lattice samples, cube codes, triangle counts, ambiguity test, records and
+// per-segment counts; then the code rows the walk left pending are stored whole.
+//
+// The entry -> (row, lane) map is computed here, per 64-entry chunk, from the per-row masks: an
+// exclusive scan of the rows' popcounts (lane = row) gives each row's first entry; the rows drop a
+// marker at that position of a 64-slot LDS strip and a max-scan spreads it; the lane inside the row is
+// the k-th set bit of the row's mask.  (Staging (row, lane) pairs from the walk, one row at a time,
+// cost ~25 scalar + ~10 vector instructions per row; the walk is bound by the CU's one scalar unit.)
+// A chunk ends at a row boundary (a row has at most 64 entries), so each row's dwords sit in one chunk's
+// registers when its code row is assembled.
+//
+// It issues NO vector-memory load: the coordinates it needs come from LDS copies of the tile's table
+// slices (tl) made before the walk's first store.  vmcnt retires in order, so a load issued here would
+// have to wait for every code store the wave still has in flight.
+//
+// TAIL = true: tail tile (lane = row, one dword per row, chunk lane 0): the dwords go to tailbuf[row]
+// (LDS) for the tile's one coalesced store instead of into whole code rows.
+// Records: collected in LDS (recbuf, MC_REC_CAP) in entry order -- segment by segment -- and appended to the
+// dense global array by flush_records(): one atomic bump per tile (rarely more), coalesced copy.  Returns in
+// lane j the global index of row j's first record.
 template <bool TAIL = false>
-__device__ __forceinline__ void mc_record_pass(const McParams& p, const McTileCtx& t, const McTileLds& tl,
-                                               const unsigned short* s_lut, const unsigned short* ent_pos, u32* seg_cnt,
-                                               const u64* row_all, const u64* row_mix, u32 nent,
-                                               u8* __restrict__ codes, u32* __restrict__ recs, u32* tailbuf = nullptr) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+__device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t, const McTileLds& tl, const unsigned short* s_lut,
+                                          u32* marker, u32* seg_cnt, u32* recbuf, u32* rowoff, const McRowMasks& rm, u64 rowPend,
+                                          u32 vmask_row, u8* __restrict__ codes, u32* __restrict__ recs, u32* tailbuf = nullptr) {
     const int n1 = p.n1;
     const float zk = tl.zk, zk1 = tl.zk1;
     const float iso = p.iso;
     const int xl0 = t.ch * MC_SEG + t.lane * 4;  // this lane's cells when it acts as a ROW lane
-    const u32 vmask_row = (xl0 + 3 < n1) ? 0xFFFFFFFFu : (xl0 + 2 < n1) ? 0x00FFFFFFu : (xl0 + 1 < n1) ? 0x0000FFFFu
-                          : (xl0 < n1) ? 0x000000FFu : 0u;
+    // lane = row: entries of the row, and the index of its first entry
+    const u32 cnt = (u32)__builtin_popcount(rm.mixlo) + (u32)__builtin_popcount(rm.mixhi);
+    const u32 incl = wave_inclusive_scan(cnt);
+    const u32 off = incl - cnt;
+    u8* __restrict__ tilebase = codes + ((u64)t.lz * n1 + t.y0) * p.pitch;
+    u64 pend = rowPend;
     u32 e0 = 0;
-    while (e0 < nent) {
-        // a chunk = up to 64 entries, cut at a row boundary (a row has at most 64 entries, and the
-        // list is sorted by row), so every row is completed inside one chunk
-        const u32 e = e0 + (u32)t.lane;
-        const bool avail = e < nent;
-        const u32 pos = avail ? ent_pos[e] : 0xFFFFu;
-        const int jraw = (int)(pos >> 6);
-        u32 ntake = min(64u, nent - e0);
-        if (e0 + 64u < nent) {
-            const int jnext = (int)(ent_pos[e0 + 64u] >> 6);
-            const int jlast = __builtin_amdgcn_readlane(jraw, 63);
-            if (jnext == jlast) ntake = (u32)__builtin_popcountll(__ballot(jraw != jlast));
-        }
-        const bool valid = (u32)t.lane < ntake;
-        const int j = valid ? jraw : 1023, ln = (int)(pos & 63u);
-        const int jj = valid ? j : 0;
-        const int x0 = t.ch * MC_SEG + ln * 4;
-        // the 20 lattice samples of the lane's 4 cells: same mc_f, same operands, same compare as
-        // everywhere else (marching.cpp:475-479, :497-505)
-        const float yl = tl.ys[jj], yu = tl.ys[jj + 1];
-        u32 sb = 0;  // bit (4*c + 2*r + pl): sample x0+c, row r (0 lower / 1 upper), plane pl
-#ifdef MC_CONS
-        u32 ob = 0;  // same layout: the sample is inside every enabled constraint (marching.cpp:255-280)
-#endif
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const float x = tl.xs[ln * 4 + c];
-            sb |= (mc_f(x, yl, zk) > iso ? 1u : 0u) << (4 * c + 0);
-            sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
-            sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
-            sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
-#ifdef MC_CONS
-            ob |= (mc_ok(x, yl, zk) ? 1u : 0u) << (4 * c + 0);
-            ob |= (mc_ok(x, yl, zk1) ? 1u : 0u) << (4 * c + 1);
-            ob |= (mc_ok(x, yu, zk) ? 1u : 0u) << (4 * c + 2);
-            ob |= (mc_ok(x, yu, zk1) ? 1u : 0u) << (4 * c + 3);
-#endif
-        }
-        // cube code bit i <-> corner i (marching.cpp:471-472): with s = nibble of sample c and
-        // n = nibble of sample c+1:  0:(x0,y0,z0)=s.0  1:(x1,y0,z0)=n.0  2:(x1,y1,z0)=n.2  3:(x0,y1,z0)=s.2
-        //                            4:(x0,y0,z1)=s.1  5:(x1,y0,z1)=n.1  6:(x1,y1,z1)=n.3  7:(x0,y1,z1)=s.3
-        u32 dw = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32 sN = (sb >> (4 * c)) & 0xFu, nN = (sb >> (4 * c + 4)) & 0xFu;
-            const u32 code = (sN & 1u) | ((nN & 1u) << 1) | (((nN >> 2) & 1u) << 2) | (((sN >> 2) & 1u) << 3) |
-                             (((sN >> 1) & 1u) << 4) | (((nN >> 1) & 1u) << 5) | (((nN >> 3) & 1u) << 6) |
-                             (((sN >> 3) & 1u) << 7);
-#ifdef MC_CONS
-            // a cell with a corner outside a constraint is skipped (marching.cpp:476): no triangles, code 0
-            if (((ob >> (4 * c)) & 0xFFu) != 0xFFu) continue;
-#endif
-            if (x0 + c < n1) dw |= code << (8 * c);
-        }
-
-        // per cell: triangle count and ambiguity flip; meta nibble c = count | flip<<3
-        u32 meta = 0, packed = 0;  // packed = triangles | active cells << 16 of this entry
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int code = valid ? (int)((dw >> (8 * c)) & 0xFF) : 0;
-            if (code != 0 && code != 255) {
-                const u32 lut = s_lut[code];
-                u32 nt = lut & 0xFFu, flip = 0;
-                const int face = (int)(lut >> 8);
-                if (face != 0xFF) {
-                    const float uz[2] = {tl.uz0, tl.uz1};
-                    if (amb_flip(p, face, tl.ux + (ln * 4 + c), tl.uy + jj, uz)) {
-                        nt = s_lut[255 - code] & 0xFFu;
-                        flip = 1;
-                    }
-                }
-                meta |= (nt | (flip << 3)) << (4 * c);
-                packed += nt + (1u << 16);
+    u32 nbuf = 0;          // records waiting in recbuf
+    u64 epochRows = 0ull;  // rows whose records are in recbuf
+    u32 rowbase = 0u;      // lane = row: global index of the row's first record
+    auto flush_records = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nbuf) {
+            // SCALAR atomic: its result comes back through lgkmcnt.  A vector atomic's would come through
+            // vmcnt, which retires in order -- the wave would sit until every code store it has in flight had
+            // landed before it could even start copying its records (measured: 0.36 -> 0.44 ms).
+            u32 gb;
+            {
+                u32* const cur = p.rec_cursor + 32u * (1u + t.region);
+                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(gb) : "s"(cur), "0"(nbuf) : "memory");
             }
+            const u32 rsize = (u32)(p.cap_recs / MC_NCUR);
+            // past the region's end nothing is written and the overflow word is raised: the host grows the
+            // buffer and sweeps again; mc_emit sees the word and stays out
+            if (gb + nbuf <= rsize) {
+                gb += t.region * rsize;
+                for (u32 i = (u32)t.lane; i < nbuf; i += 64u) recs[gb + i] = recbuf[i];
+            } else if (t.lane == 0) {
+                p.rec_cursor[0] = 1u;
+            }
+            if ((epochRows >> t.lane) & 1ull) rowbase = gb + rowoff[t.lane];
         }
-        // prefix inside each segment (= tile row j): wave scan minus the scan value at the
-        // segment's first entry; both halves of `packed` are non-decreasing, so a max-scan of
-        // "exclusive value at segment heads" propagates the base to the followers.
-        const u32 incl = wave_inclusive_scan(packed);
-        const u32 excl = incl - packed;
-        const int jprev = __builtin_amdgcn_update_dpp(-1, j, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const bool head = valid && (t.lane == 0 || jprev != j);
-        const u32 base = wave_inclusive_max(head ? excl : 0u);
-        const u32 pre = excl - base;
-        if (valid) {
-            // segment totals: order-independent LDS adds; slot j is read by lane j at tile end
-            if (packed) __hip_atomic_fetch_add(&seg_cnt[j], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            u32* __restrict__ rseg = recs + (t.seg0 + (u64)j * p.nchunk) * MC_SEG;
-            u32 rank = pre >> 16, tpre = pre & 0xFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nbuf = 0u;
+        epochRows = 0ull;
+    };
+    while (pend) {
+        // the rows this chunk completes: the leading pending rows that end within 64 entries (ends are monotone)
+        const u64 fit = __ballot(incl <= e0 + 64u) & pend;
+        const int jl = 63 - __builtin_clzll(fit);  // fit != 0: the first pending row starts at e0 and has <= 64 entries
+        const u32 e1 = (u32)__builtin_amdgcn_readlane((int)incl, jl);
+        const u32 ntake = e1 - e0;
+        u32 dw = 0;
+        if (ntake) {
+            if (nbuf + 256u > MC_REC_CAP) flush_records();  // a chunk adds at most 64 * 4 records
+            marker[t.lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (((fit >> t.lane) & 1ull) && cnt) marker[off - e0] = (u32)t.lane + 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool valid = (u32)t.lane < ntake;
+            const int row1 = (int)wave_inclusive_max(marker[t.lane]);  // row + 1 of the entry on this lane
+            const int jj = valid ? row1 - 1 : 0;
+            const int j = valid ? row1 - 1 : 1023;
+            // (all three shuffles outside any lane-dependent control flow: a ds_bpermute reads 0 from a lane
+            // that is switched off, and the row lanes are not the entry lanes)
+            const u32 roff = (u32)__shfl((int)off, jj, 64);
+            const u32 rmlo = (u32)__shfl((int)rm.mixlo, jj, 64), rmhi = (u32)__shfl((int)rm.mixhi, jj, 64);
+            const u32 k = (e0 + (u32)t.lane) - roff;
+            const int ln = valid ? nth_set_bit64(rmlo, rmhi, k) : 0;
+            const int x0 = t.ch * MC_SEG + ln * 4;
+            // the 20 lattice samples of the lane's 4 cells: same mc_f, same operands, same compare as
+            // everywhere else (marching.cpp:475-479, :497-505)
+            const float yl = tl.ys[jj], yu = tl.ys[jj + 1];
+            u32 sb = 0;  // bit (4*c + 2*r + pl): sample x0+c, row r (0 lower / 1 upper), plane pl
+#ifdef MC_CONS
+            u32 ob = 0;  // same layout: the sample is inside every enabled constraint (marching.cpp:255-280)
+#endif
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const float x = tl.xs[ln * 4 + c];
+                sb |= (mc_f(x, yl, zk) > iso ? 1u : 0u) << (4 * c + 0);
+                sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
+                sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
+                sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
+#ifdef MC_CONS
+                ob |= (mc_ok(x, yl, zk) ? 1u : 0u) << (4 * c + 0);
+                ob |= (mc_ok(x, yl, zk1) ? 1u : 0u) << (4 * c + 1);
+                ob |= (mc_ok(x, yu, zk) ? 1u : 0u) << (4 * c + 2);
+                ob |= (mc_ok(x, yu, zk1) ? 1u : 0u) << (4 * c + 3);
+#endif
+            }
+            // cube code bit i <-> corner i (marching.cpp:471-472): with s = nibble of sample c and
+            // n = nibble of sample c+1:  0:(x0,y0,z0)=s.0  1:(x1,y0,z0)=n.0  2:(x1,y1,z0)=n.2  3:(x0,y1,z0)=s.2
+            //                            4:(x0,y0,z1)=s.1  5:(x1,y0,z1)=n.1  6:(x1,y1,z1)=n.3  7:(x0,y1,z1)=s.3
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const u32 m = (meta >> (4 * c)) & 0xFu;
-                const u32 nt = m & 7u;
-                if (nt) {
-                    rseg[rank++] = (u32)(ln * 4 + c) | (((dw >> (8 * c)) & 0xFFu) << 8) | ((m >> 3) << 16) | (nt << 17) |
-                                   (tpre << 20);
-                    tpre += nt;
+                const u32 sN = (sb >> (4 * c)) & 0xFu, nN = (sb >> (4 * c + 4)) & 0xFu;
+                const u32 code = (sN & 1u) | ((nN & 1u) << 1) | (((nN >> 2) & 1u) << 2) | (((sN >> 2) & 1u) << 3) |
+                                 (((sN >> 1) & 1u) << 4) | (((nN >> 1) & 1u) << 5) | (((nN >> 3) & 1u) << 6) |
+                                 (((sN >> 3) & 1u) << 7);
+#ifdef MC_CONS
+                // a cell with a corner outside a constraint is skipped (marching.cpp:476): no triangles, code 0
+                if (((ob >> (4 * c)) & 0xFFu) != 0xFFu) continue;
+#endif
+                if (x0 + c < n1) dw |= code << (8 * c);
+            }
+            if (!valid) dw = 0u;
+
+            // per cell: triangle count and ambiguity flip; meta nibble c = count | flip<<3
+            u32 meta = 0, packed = 0;  // packed = triangles | active cells << 16 of this entry
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int code = (int)((dw >> (8 * c)) & 0xFF);
+                if (code != 0 && code != 255) {
+                    const u32 lut = s_lut[code];
+                    u32 nt = lut & 0xFFu, flip = 0;
+                    const int face = (int)(lut >> 8);
+                    if (face != 0xFF) {
+                        const float uz[2] = {tl.uz0, tl.uz1};
+                        if (amb_flip(p, face, tl.ux + (ln * 4 + c), tl.uy + jj, uz)) {
+                            nt = s_lut[255 - code] & 0xFFu;
+                            flip = 1;
+                        }
+                    }
+                    meta |= (nt | (flip << 3)) << (4 * c);
+                    packed += nt + (1u << 16);
                 }
             }
+            // prefix inside each segment (= tile row j): wave scan minus the scan value at the
+            // segment's first entry; both halves of `packed` are non-decreasing, so a max-scan of
+            // "exclusive value at segment heads" propagates the base to the followers.
+            const u32 pincl = wave_inclusive_scan(packed);
+            const u32 excl = pincl - packed;
+            const int jprev = __builtin_amdgcn_update_dpp(-1, j, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const bool head = valid && (t.lane == 0 || jprev != j);
+            const u32 base = wave_inclusive_max(head ? excl : 0u);
+            const u32 pre = excl - base;
+            if (valid) {
+                // segment totals: order-independent LDS adds; slot j is read by lane j at tile end
+                if (packed) __hip_atomic_fetch_add(&seg_cnt[j], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                u32 bpos = nbuf + (excl >> 16), tpre = pre & 0xFFFFu;  // records are buffered in entry order
+                if (head) rowoff[j] = bpos;                           // the row's (= segment's) first record
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32 m = (meta >> (4 * c)) & 0xFu;
+                    const u32 nt = m & 7u;
+                    if (nt) {
+                        recbuf[bpos++] = (u32)(ln * 4 + c) | (((dw >> (8 * c)) & 0xFFu) << 8) | ((m >> 3) << 16) | (nt << 17) |
+                                         (tpre << 20);
+                        tpre += nt;
+                    }
+                }
+                if (TAIL) tailbuf[j] = dw;
+            }
+            nbuf += (u32)__builtin_amdgcn_readlane((int)pincl, 63) >> 16;
         }
-        // the code rows of this chunk, each written WHOLE (256 B, full 128-byte lines): the listed
-        // lanes' dwords come from the entry lanes (ds_bpermute), the others are 0 / ~0 by the walk's
-        // per-lane masks.  (Writing only the listed dwords here and the rest in the walk made
-        // every such line a partial write -- a read-modify-write in HBM; measured.)
-        if (TAIL) {
-            if (valid) tailbuf[j] = dw;
-            e0 += ntake;
-            continue;
-        }
-        u64 heads = __ballot(head);
-        while (heads) {
-            const int h = __builtin_ctzll(heads);
-            heads &= heads - 1ull;
-            const int jr = __builtin_amdgcn_readlane(j, h);
-            const u64 mix = row_mix[jr];
-            // row lane L is listed iff bit L of mix; its entry sits at chunk lane h + rank(L)
-            const u32 mine = (u32)__shfl((int)dw, h + (int)mask_rank(mix), 64);
-            const u32 v = select_by_mask(mix, mine, select_by_mask(row_all[jr], vmask_row, 0u));
+        epochRows |= fit;
+        if (!TAIL) {
+            // the pending code rows this chunk completes, each written WHOLE (256 B, full 128-byte lines):
+            // the listed lanes' dwords come from the entry lanes (ds_bpermute), the others are 0 / ~0 by the
+            // walk's per-lane masks.  (Writing only the listed dwords here and the rest in the walk made
+            // every such line a partial write -- a read-modify-write in HBM; measured.)
+            u64 f = fit;
+            while (f) {
+                const int jr = __builtin_ctzll(f);
+                f &= f - 1ull;
+                const u64 mix = ((u64)(u32)__builtin_amdgcn_readlane((int)rm.mixhi, jr) << 32) | (u32)__builtin_amdgcn_readlane((int)rm.mixlo, jr);
+                const u64 all = ((u64)(u32)__builtin_amdgcn_readlane((int)rm.allhi, jr) << 32) | (u32)__builtin_amdgcn_readlane((int)rm.alllo, jr);
+                const int first = (int)((u32)__builtin_amdgcn_readlane((int)off, jr) - e0);  // chunk lane of the row's first entry
+                // row lane L is listed iff bit L of mix; its entry sits at chunk lane first + rank(L)
+                const u32 mine = (u32)__shfl((int)dw, first + (int)mask_rank(mix), 64);
+                const u32 v = select_by_mask(mix, mine, select_by_mask(all, vmask_row, 0u));
 #ifndef MC_DBG_NO_STORE
-            __builtin_amdgcn_raw_buffer_store_b32(
-                v, __builtin_amdgcn_make_buffer_rsrc(codes + ((u64)t.lz * n1 + t.y0 + jr) * p.pitch, 0, (int)p.pitch, 0x00020000),
-                (u32)xl0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)jr * (u32)p.pitch), 0, (int)p.pitch, 0x00020000), (u32)xl0, 0, 0);
 #else
-            asm volatile("" ::"v"(v));
+                asm volatile("" ::"v"(v));
 #endif
+            }
         }
-        e0 += ntake;
+        pend &= ~fit;
+        e0 = e1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    flush_records();
+    return rowbase;
 }
 
+
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
-                                                                         u32* __restrict__ segcnt, u32* __restrict__ recs,
+                                                                         uint2* __restrict__ segcb, u32* __restrict__ recs,
                                                                          u64* __restrict__ grpsum) {
     __shared__ unsigned short s_lut[256];  // triangle count | ambiguity face << 8
-    __shared__ unsigned short s_ent_pos[MC_WPB_C][MC_ENT_CAP + 64];  // + one dump slot per lane
+    __shared__ u32 s_marker[MC_WPB_C][64];   // back-end: first-entry markers of a 64-entry chunk
+    __shared__ u32 s_rowoff[MC_WPB_C][64];   // back-end: position of each row's first record in s_recbuf
+    __shared__ u32 s_recbuf[MC_WPB_C][MC_REC_CAP];  // back-end: the tile's records before they are appended to recs
+    __shared__ u32 s_tailbuf[MC_WPB_C][64];  // tail tiles: the rows' code dwords
     __shared__ u32 s_segcnt[MC_WPB_C][64];
     __shared__ float s_tab[MC_WPB_C][2 * 264 + 2 * 72];  // per wave: xs[264] ux[264] ys[72] uy[72] (table slices)
-    __shared__ u64 s_rowall[MC_WPB_C][64], s_rowmix[MC_WPB_C][64];  // per tile row: lanes all-above / lanes listed
 #pragma unroll
     for (int i = (int)threadIdx.x; i < 256; i += 64 * MC_WPB_C)
         s_lut[i] = (unsigned short)(c_tri_count[i] | (c_amb_face[i] << 8));
@@ -483,10 +581,10 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     const int x0 = ch * MC_SEG + lane * 4;
     const float iso = p.iso;
 
-    unsigned short* ent_pos = s_ent_pos[w];
     u32* seg_cnt = s_segcnt[w];
-    u64* row_all = s_rowall[w];
-    u64* row_mix = s_rowmix[w];
+    u32* marker = s_marker[w];
+    u32* recbuf = s_recbuf[w];
+    u32* rowoff = s_rowoff[w];
     seg_cnt[lane] = 0u;
 
     const float* __restrict__ ax = p.axs;
@@ -546,6 +644,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         tt.lz = lz;
         tt.lane = lane;
         tt.seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;
+        tt.region = (u32)tile & (MC_NCUR - 1u);
         const bool rvalid = lane < ny;
         const u32 vm = p.tail_cells >= 4 ? 0xFFFFFFFFu : ((1u << (8 * p.tail_cells)) - 1u);
         u64 laneAll = 0ull, mixedL;
@@ -570,11 +669,15 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 #else
         mixedL = __ballot(rvalid);  // no enclosure for this equation: the record pass evaluates every row
 #endif
-        u32* tailbuf = (u32*)row_all;
-        const u32 cnt = (u32)__builtin_popcountll(mixedL);
-        ent_pos[select_by_mask(mixedL, mask_rank(mixedL), (u32)(MC_ENT_CAP + lane))] = (unsigned short)(lane << 6);
+        u32* tailbuf = s_tailbuf[w];
+        McRowMasks rmt;
+        rmt.mixlo = (u32)((mixedL >> lane) & 1ull);  // lane = row: its one entry is chunk lane 0
+        rmt.mixhi = 0u;
+        rmt.alllo = 0u;
+        rmt.allhi = 0u;
+        u32 rbase = 0u;
 #ifndef MC_DBG_NO_RECORD
-        if (cnt) mc_record_pass<true>(p, tt, tl, s_lut, ent_pos, seg_cnt, row_all, row_mix, cnt, codes, recs, tailbuf);
+        if (mixedL) rbase = mc_backend<true>(p, tt, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rmt, mixedL, 0u, codes, recs, tailbuf);
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -585,7 +688,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 #endif
             const u64 sg = tt.seg0 + (u64)lane * p.nchunk;
             const u32 c = seg_cnt[lane];
-            segcnt[sg] = c;
+            segcb[sg] = make_uint2(c, rbase);
             if (c) atomicAdd(&grpsum[sg >> 6], (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32));
         }
         return;
@@ -644,10 +747,25 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     tc.lz = lz;
     tc.lane = lane;
     tc.seg0 = ((u64)lz * n1 + y0) * p.nchunk + ch;
-    u32 nent = 0;
+    tc.region = (u32)tile & (MC_NCUR - 1u);
+    // what the walk hands to the back-end: per-row lane masks (lane j = row j) and the rows whose code row
+    // it has not stored
+    McRowMasks rm = {0u, 0u, 0u, 0u};
+    u64 rowPend = 0ull;
+#define MC_SET_ROW(j_, mixed_, all_)                                                                          \
+    {   /* v_writelane: with an SGPR value the lane select must be M0 (constant-bus limit); M0 is restored */ \
+        const u64 mx_ = (mixed_), al_ = (all_);                                                               \
+        u32 m0save_;                                                                                          \
+        asm("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %6, m0\n\t"                \
+            "v_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\t"        \
+            "s_mov_b32 m0, %4"                                                                                \
+            : "+v"(rm.mixlo), "+v"(rm.mixhi), "+v"(rm.alllo), "+v"(rm.allhi), "=&s"(m0save_)                  \
+            : "s"((int)(j_)), "s"((u32)mx_), "s"((u32)(mx_ >> 32)), "s"((u32)al_), "s"((u32)(al_ >> 32)));     \
+    }
 
     // row base of the code plane as a wave-uniform pointer + 32-bit lane offset
-    u8* __restrict__ rowbase = codes + ((u64)lz * n1 + y0) * p.pitch;
+    u8* const tilebase = codes + ((u64)lz * n1 + y0) * p.pitch;
+    u8* __restrict__ rowbase = tilebase;
     const u32 xoff = (u32)x0;
     // Code stores go through a buffer descriptor over ONE row, rebuilt per step by advancing its
     // (scalar) base: lanes beyond the end of the row are dropped by the hardware range check
@@ -666,23 +784,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 #endif
         rowbase += p.pitch;
     };
-    // lanes that may hold surface cells note (row, lane) in the LDS list; every lane writes, the
-    // others into a per-lane dump slot (no exec juggling)
-    auto stage = [&](int j, u64 mixedL, u64 laneAll) {
-        const u32 cnt = (u32)__builtin_popcountll(mixedL);
-        if (nent + cnt > MC_ENT_CAP) {
-            mc_record_pass(p, tc, tl, s_lut, ent_pos, seg_cnt, row_all, row_mix, nent, codes, recs);
-            nent = 0;
-        }
-        const u32 idx = select_by_mask(mixedL, nent + mask_rank(mixedL), (u32)(MC_ENT_CAP + lane));
-        ent_pos[idx] = (unsigned short)((j << 6) | lane);
-        if (lane == 0) {
-            row_all[j] = laneAll;
-            row_mix[j] = mixedL;
-        }
-        nent += cnt;
-    };
-
 #if defined(MC_HAVE_IV) && defined(MC_FINITE) && !defined(MC_NO_CULL)
     // ---- interval walk: no sample is evaluated here at all.  A row the tile-level test could
     // not decide is classified per LANE by one more interval evaluation over the lane's own box
@@ -710,32 +811,70 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         const u32 xbyte = (u32)(ch * MC_SEG + k4 * 4);
         const u32 woff = (xbyte < (u32)p.pitch) ? (u32)q * (u32)p.pitch + xbyte : 0x80000000u;
         const int wbytes = (int)(3u * (u32)p.pitch + (u32)p.pitch);
-        for (int j = 0; j < ny; ++j) {
-            if ((j & 3) == 0 && j + 3 < ny && ((rowCull >> j) & 0xFull) == 0xFull) {
-                const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
-#ifndef MC_DBG_NO_STORE
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 v;
-                v.x = c & vm4[0];
-                v.y = c & vm4[1];
-                v.z = c & vm4[2];
-                v.w = c & vm4[3];
-                __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, wbytes, 0x00020000),
-                                                       woff, 0, 0);
+        // The rows are handled class by class, each class by iterating the set bits of its mask: the CU has
+        // ONE scalar unit, and a per-row "which kind of row is this" decision tree cost more scalar
+        // instructions than the work itself (measured: 135 M scalar vs 100 M vector instructions per sweep).
+        // lxl / lxh come from loads issued at the top of the tile; consume them BEFORE the first store: the
+        // compiler otherwise waits for them at their first use, after the store loops, and with in-order
+        // vmcnt that wait is "until every store above has landed" (measured: the tile's compute then starts
+        // only when its culled rows are in memory -- compute + store time instead of the larger of the two)
+        asm volatile("" ::"v"(lxl), "v"(lxh), "v"(yv));
+        const u64 rowsValid = (1ull << ny) - 1ull;  // ny <= 63 here
+        const u64 cull = rowCull & rowsValid;
+#ifndef MC_STORES_LAST
+        // (1) aligned blocks of 4 culled rows
+        u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
+        const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
+#ifdef MC_DBG_NO_CULLSTORE
+        m4 = 0ull;
 #endif
-                rowbase += 4 * p.pitch;
-                j += 3;
-                continue;
-            }
-            if ((rowCull >> j) & 1ull) {  // proven uniform by the tile-level test
-                store_codes(((rowFull >> j) & 1ull) ? vmask : 0u);
-                continue;
-            }
-            // two undecided rows in a row share ONE lane-level evaluation over the box of both (3 sample
-            // rows): half the interval evaluations, for a few more lanes handed to the record pass
-            // (which is exact, so a lane listed needlessly just yields uniform codes and no record)
+        while (m4) {
+            const int j = __builtin_ctzll(m4);
+            m4 &= m4 - 1ull;
+            const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
+#ifndef MC_DBG_NO_STORE
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v;
+            v.x = c & vm4[0];
+            v.y = c & vm4[1];
+            v.z = c & vm4[2];
+            v.w = c & vm4[3];
+            __builtin_amdgcn_raw_buffer_store_b128(
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, 0);
+#else
+            asm volatile("" ::"v"(c));
+#endif
+        }
+        // (2) the other culled rows
+        u64 m1 = cull & ~blockRows;
+#ifdef MC_DBG_NO_CULLSTORE
+        m1 = 0ull;
+#endif
+        while (m1) {
+            const int j = __builtin_ctzll(m1);
+            m1 &= m1 - 1ull;
+            const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
+#ifndef MC_DBG_NO_STORE
+            __builtin_amdgcn_raw_buffer_store_b32(
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, 0);
+#else
+            asm volatile("" ::"v"(v));
+#endif
+        }
+#endif
+        // (3) undecided rows: the lane-level masks go to lane j of rm, the row itself to the back-end.
+        // Two adjacent undecided rows share ONE evaluation over the box of both (3 sample rows): half
+        // the interval evaluations, for a few more lanes handed to the back-end (which is exact, so a
+        // lane listed needlessly just yields uniform codes and no record).
+        rowPend = rowsValid & ~cull;
+        const u64 lanesIn = __ballot(x0 < n1);  // lanes that hold cells of the grid (a ragged last chunk has fewer)
+        u64 mu = rowPend;
+        while (mu) {
+            const int j = __builtin_ctzll(mu);
+            mu &= mu - 1ull;
 #ifndef MC_NO_PAIR
-            const int pair = (j + 1 < ny && !((rowCull >> (j + 1)) & 1ull)) ? 1 : 0;
+            const int pair = (int)((mu >> ((j + 1) & 63)) & 1ull);  // row j+1 is undecided too (j + 1 < ny then)
+            if (pair) mu &= mu - 1ull;
 #else
             const int pair = 0;
 #endif
@@ -746,21 +885,55 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             bool allok, dead;
             mc_ok_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, allok, dead);
             const u64 laneAll = __ballot(lo > iso && allok);
-            const u64 mixedL = __ballot(hi > iso && !dead) & ~laneAll;
+            const u64 mixedL = __ballot(hi > iso && !dead) & ~laneAll & lanesIn;
 #else
             const u64 laneAll = __ballot(lo > iso);
-            const u64 mixedL = __ballot(hi > iso) & ~laneAll;
+            const u64 mixedL = __ballot(hi > iso) & ~laneAll & lanesIn;
 #endif
-            for (int r = 0; r <= pair; ++r) {
-                if (mixedL) {  // the record pass writes this row whole
-                    stage(j + r, mixedL, laneAll);
-                    rowbase += p.pitch;
-                } else {
-                    store_codes(select_by_mask(laneAll, vmask, 0u));
-                }
-            }
-            j += pair;
+            MC_SET_ROW(j, mixedL, laneAll)
+            if (pair) MC_SET_ROW(j + 1, mixedL, laneAll)
         }
+#ifdef MC_STORES_LAST
+        // (1) aligned blocks of 4 culled rows
+        u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
+        const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
+#ifdef MC_DBG_NO_CULLSTORE
+        m4 = 0ull;
+#endif
+        while (m4) {
+            const int j = __builtin_ctzll(m4);
+            m4 &= m4 - 1ull;
+            const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
+#ifndef MC_DBG_NO_STORE
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v;
+            v.x = c & vm4[0];
+            v.y = c & vm4[1];
+            v.z = c & vm4[2];
+            v.w = c & vm4[3];
+            __builtin_amdgcn_raw_buffer_store_b128(
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, 0);
+#else
+            asm volatile("" ::"v"(c));
+#endif
+        }
+        // (2) the other culled rows
+        u64 m1 = cull & ~blockRows;
+#ifdef MC_DBG_NO_CULLSTORE
+        m1 = 0ull;
+#endif
+        while (m1) {
+            const int j = __builtin_ctzll(m1);
+            m1 &= m1 - 1ull;
+            const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
+#ifndef MC_DBG_NO_STORE
+            __builtin_amdgcn_raw_buffer_store_b32(
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, 0);
+#else
+            asm volatile("" ::"v"(v));
+#endif
+        }
+#endif
     }
 #else
     // ---- sampling walk (equations the interval code cannot bound: division by a variable,
@@ -842,8 +1015,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 #endif
             const u64 laneAll = allOwn & nbAll;
             const u64 mixedL = (anyOwn | nbAny) & ~laneAll;  // lanes with corners on both sides of iso
-            if (mixedL) {  // the record pass writes this row whole
-                stage(j, mixedL, laneAll);
+            if (mixedL) {  // the back-end writes this row whole
+                MC_SET_ROW(j, mixedL, laneAll)
+                rowPend |= 1ull << j;
                 rowbase += p.pitch;
             } else {
                 store_codes(select_by_mask(laneAll, vmask, 0u));
@@ -865,15 +1039,17 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 
 #endif  // interval / sampling walk
 
+#undef MC_SET_ROW
+    u32 rbase = 0u;
 #ifndef MC_DBG_NO_RECORD
-    if (nent) mc_record_pass(p, tc, tl, s_lut, ent_pos, seg_cnt, row_all, row_mix, nent, codes, recs);
+    if (rowPend) rbase = mc_backend(p, tc, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rm, rowPend, vmask, codes, recs);
 #endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < ny) {
         const u64 sg = tc.seg0 + (u64)lane * p.nchunk;
         const u32 c = seg_cnt[lane];
-        segcnt[sg] = c;
+        segcb[sg] = make_uint2(c, rbase);
         // group sums for the scan (group = 64 consecutive segments): triangles | active cells << 32
         if (c) atomicAdd(&grpsum[sg >> 6], (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32));
     }
@@ -918,7 +1094,7 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
 // evaluations, the interpolation, the central-difference gradient of f for the normal, 24-byte
 // store.
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
-                                                                     const u32* __restrict__ segcnt, const uint2* __restrict__ grpoff,
+                                                                     const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                      float* __restrict__ verts, unsigned short* __restrict__ trimeta) {
     __shared__ u64 s_row[256];
     __shared__ u8 s_edge[16];
@@ -926,6 +1102,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
     __shared__ u32 s_seg[MC_WPB_E][64];
     __shared__ u32 s_act[MC_WPB_E][66];
     __shared__ u32 s_tri[MC_WPB_E][64];
+    __shared__ u32 s_rbase[MC_WPB_E][64];
     // the whole lattice coordinate table (n1+1 <= 2002 floats): the vertex phase gathers 6
     // coordinates per vertex, and vmcnt retires in order -- a global gather issued after the
     // previous iteration's vertex stores would wait for those stores to land
@@ -943,7 +1120,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
     const u32 seg_first = group * 64u;
     const u32 seg = seg_first + (u32)lane;
     const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
-    const u32 cnt = seg < p.nseg ? segcnt[seg] : 0u;
+    const uint2 cb = seg < p.nseg ? segcb[seg] : make_uint2(0u, 0u);  // {triangles | active << 16, first record}
+    const u32 cnt = cb.x;
+    const u32 rec_overflow = p.rec_cursor[0];
     {
         // issue every table load before the first wait: a copy loop would pay one full memory
         // latency per iteration (the compiler waits for each load before its LDS store)
@@ -968,7 +1147,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
             if ((int)threadIdx.x + NT * k < 256) s_row[(int)threadIdx.x + NT * k] = trow[k];
         if (threadIdx.x < 12) s_edge[threadIdx.x] = tedge;
     }
-    const bool mine = in_range && g0.y != g1.y;  // this wave's 64 segments hold an active cell
+    // rec_overflow: mc_classify ran out of record space (the host grows the buffer and sweeps again)
+    const bool mine = in_range && g0.y != g1.y && rec_overflow == 0u;  // 64 segments with an active cell
     if (!__syncthreads_or(mine ? 1 : 0)) return;  // also the barrier that publishes the tables
     if (!mine) return;
     {
@@ -984,6 +1164,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
     u32* segrec = s_seg[w];
     u32* actoff = s_act[w];
     u32* trioff = s_tri[w];
+    u32* rbase = s_rbase[w];
     const int n1 = p.n1;
     {
         const u32 sg = min(seg, p.nseg - 1u);
@@ -994,6 +1175,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
         segrec[lane] = iy | ((u32)(p.z_begin + (int)lz) << 11) | (ch << 22);
         actoff[lane] = o0.y - act_base;
         trioff[lane] = o0.x;
+        rbase[lane] = cb.y;
         if (lane == 63) actoff[64] = nrec;
     }
     const float h = 0.5f * p.step;
@@ -1114,7 +1296,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
         }
         u32 rec = 0, gtri0 = 0;
         if (valid) {
-            rec = recs[((u64)seg_first + lo) * MC_SEG + (r - actoff[lo])];
+            rec = recs[rbase[lo] + (r - actoff[lo])];
             gtri0 = trioff[lo] + (rec >> 20);
         }
         const u32 nt = (rec >> 17) & 7u;

@@ -366,3 +366,22 @@ def test_constraint_errors(mc):
                 c.set_constraint(*args)
     finally:
         c.close()
+
+
+def test_record_buffer_grows_on_demand(mc, orc, monkeypatch):
+    """The dense record array starts from a guess; a surface with more active cells overflows it, the sweep's own
+    count tells the host, which grows the buffer and sweeps again (same path a replayed graph takes)."""
+    monkeypatch.setenv("MC_REC_CAP0", "64")
+    c = mc.Context(0)
+    try:
+        eq, step = EQ["sphere"], step_of(40)
+        r = c.march(eq, step)
+        o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=3)
+        assert r.n_active > 64 and (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+        assert np.array_equal(r.codes(), o.codes)
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, "positions")
+        c.graph_build(eq, step, iso=0.5)            # fewer cells at iso 0.5 ...
+        g = c.graph_replay(0.0)                     # ... than at 0: the replay outgrows nothing here (already grown)
+        assert g.n_tris == o.n_tris
+    finally:
+        c.close()

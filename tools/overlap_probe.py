@@ -8,9 +8,12 @@ import mc_amd
 eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(1024))
 K = 30
 
+FLAGS = mc_amd.FLAG_NO_EMIT if "--classify-only" in sys.argv else mc_amd.FLAG_NORMALS
+
+
 def worker(ctx, n):
     for _ in range(n):
-        ctx.march(eq, step, 0.0, flags=mc_amd.FLAG_NORMALS)
+        ctx.march(eq, step, 0.0, flags=FLAGS)
 
 for nctx in (1, 2, 3):
     ctxs = [mc_amd.Context(0) for _ in range(nctx)]

@@ -30,7 +30,16 @@ if extra:
     env["MC_JIT_EXTRA"] = extra
 cmd = ["rocprofv3", "--pmc", *counters, "-d", outdir, "-o", "run", "--output-format", "csv", "--",
        sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *bench_args]
-r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+import signal
+proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+try:
+    out, _ = proc.communicate(timeout=150)
+except subprocess.TimeoutExpired:
+    os.killpg(proc.pid, signal.SIGKILL)   # the profiler starts the program as a grandchild: kill the whole group
+    print("rocprofv3 timed out (150 s); counters:", counters)
+    sys.exit(2)
+class r:  # noqa
+    stdout, stderr = out, ""
 files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
 if not files:
     print("no counter file", r.stdout[-500:], r.stderr[-1500:])
