@@ -192,6 +192,8 @@ def test_graph_replay_equals_march(mc, ctx):
     ctx.graph_build(eq, step, iso=-0.4)
     for iso in (-0.6, -0.45, -0.2, -0.4):
         g = ctx.graph_replay(iso)
+        # the per-kernel HIP events are nodes of the captured graph: the replay reports real kernel times
+        assert 0 < g.ms_classify < g.ms_total and 0 < g.ms_emit < g.ms_total and g.ms_total < 50
         gv = g.vertices()
         m = ctx.march(eq, step, iso, flags=mc.FLAG_NORMALS)
         assert g.n_tris == m.n_tris and np.array_equal(u32(gv), u32(m.vertices()))
