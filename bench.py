@@ -213,7 +213,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world, scale[0]) if world > 1 else None
+    halo = None
+    if world > 1:
+        try:  # a diagnostic outside the timed region: never let it take the measurement down
+            halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world, scale[0])
+        except Exception as e:  # noqa: BLE001
+            halo = {"error": f"{type(e).__name__}: {e}"[:200]}
     for _ in range(args.warmup):
         one_step()
     fence()

@@ -387,3 +387,24 @@ def test_record_buffer_grows_on_demand(mc, orc, monkeypatch):
         assert g.n_tris == o.n_tris
     finally:
         c.close()
+
+
+def test_largest_grid_step_0001(mc):
+    """The smallest step set_grid_step_size accepts (0.001, marching.cpp:226) = 2001 cells per axis: one 128-layer
+    slab of it (the whole grid is 8e9 cells; the slab keeps the test short) against closed-form expectations."""
+    c = mc.Context(0)
+    try:
+        step = 0.001
+        n1 = mc.cells_per_axis(step)
+        assert n1 == 2001
+        zb, ze = 936, 1064                                   # around the equator
+        r = c.march(EQ["sphere"], step, 0.0, flags=mc.FLAG_NORMALS, z_begin=zb, z_end=ze)
+        assert r.n_cells == n1 * n1 * (ze - zb)
+        # band of a unit sphere of height h has area 2*pi*h; ~2.37 triangles per unit of area/step^2 (measured at 256..1024)
+        area = 2 * np.pi * (ze - zb) * step
+        assert abs(r.n_tris / (area / step ** 2) - 2.37) < 0.08
+        v = r.vertices()[:: 1009].reshape(-1, 6)
+        assert np.abs(np.linalg.norm(v[:, :3], axis=1) - 1).max() < 2e-6
+        assert np.abs(np.sum(v[:, :3] * v[:, 3:], axis=1) - 1).max() < 1e-4   # normals point outwards (towards f > iso)
+    finally:
+        c.close()
