@@ -195,6 +195,15 @@ def main():
     ctx = mc_amd.Context(local_rank)
     cdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if world > 1 else None
+    # per-step count exchange without a host stall: the rank's count goes through a pinned slot and an async copy,
+    # the all-gather is enqueued asynchronously (stream-ordered behind it) and only the fence waits for it
+    nslots = args.steps + args.warmup + 1
+    mine_host = torch.zeros(nslots, dtype=torch.int64)
+    if cdev == "cuda":
+        mine_host = mine_host.pin_memory()
+    mine_dev = torch.zeros(nslots, dtype=torch.int64, device=cdev) if world > 1 else None
+    pending = []
+    step_no = [0]
 
     # steady state: the sweep (parameter upload, classify, scan x3, emit, totals download) is captured once as a
     # hipGraph and replayed per step -- one launch instead of a dozen API calls (~30 us of host time per sweep)
@@ -204,11 +213,20 @@ def main():
     def one_step():
         r = ctx.graph_replay(0.0) if not args.no_graph else ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
         if world > 1:  # the path's one real exchange: per-rank triangle counts -> global offsets
-            mine = torch.tensor([r.n_tris], dtype=torch.int64, device=cdev)
-            dist.all_gather_into_tensor(counts_dev, mine)
+            i = step_no[0] % nslots
+            step_no[0] += 1
+            mine_host[i] = r.n_tris
+            if cdev == "cuda":
+                mine_dev[i:i + 1].copy_(mine_host[i:i + 1], non_blocking=True)
+            else:
+                mine_dev[i] = mine_host[i]
+            pending.append(dist.all_gather_into_tensor(counts_dev, mine_dev[i:i + 1], async_op=True))
         return r
 
     def fence():
+        for wk in pending:
+            wk.wait()
+        pending.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
