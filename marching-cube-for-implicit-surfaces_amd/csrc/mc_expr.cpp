@@ -424,8 +424,8 @@ bool finite_on_domain(const Program& p, double radius) {
             break;
         }
         case NodeOp::SIN: case NodeOp::COS:
-            // mc_trig.h: finite (and within [-1, 1]) exactly when |argument| < 2^20
-            if (!(lo[n.a] > -1048000.0 && hi[n.a] < 1048000.0)) return false;
+            // mc_trig.h: finite (and within [-1, 1]) exactly when |argument| < 8192
+            if (!(lo[n.a] > -8000.0 && hi[n.a] < 8000.0)) return false;
             l = -1.0;
             h = 1.0;
             break;

@@ -65,11 +65,11 @@ __device__ __forceinline__ float mc_pow_int(float a) {
 __device__ __attribute__((noinline)) float mc_pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
 
 // ------------------------------------------------------------------ extension E1: enclosures of sin / cos
-// [lo, hi] contains every value mc_sinf COMPUTES on [l, h].  mc_sinf is within 1 ulp (<= 1.2e-7) of
-// the true sine and never exceeds 1 in magnitude, and the true sine is monotone between extrema
+// [lo, hi] contains every value mc_sinf COMPUTES on [l, h].  mc_sinf is within 1e-7 (measured 9.3e-8) of
+// the true sine and never exceeds 1 in magnitude (it clamps), and the true sine is monotone between extrema
 // (pi/2 + n*pi): if no extremum can lie in [l, h] the computed endpoint values, widened by 3e-7,
 // bound the range; an extremum that may lie inside (tested in double with a guard band) contributes
-// its +-1.  Arguments are finite and below 2^20 here (finite_on_domain, mc_expr.cpp).
+// its +-1.  Arguments are finite and below 8192 here (finite_on_domain, mc_expr.cpp).
 __device__ __forceinline__ void mc_trig_iv(float l, float h, double shift, int which, float& lo, float& hi) {
     // extrema of sin at (n + 1/2) pi, of cos at n pi: maxima for even n, minima for odd n
     const double a = (double)l * 0.31830988618379067154 - shift, b = (double)h * 0.31830988618379067154 - shift;

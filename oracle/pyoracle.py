@@ -46,7 +46,9 @@ class _Mesh(C.Structure):
 def build(force=False):
     """Compile liboracle.so (and _ref/check_tables where the reference exists)."""
     so = _HERE / "liboracle.so"
-    if force or not so.exists() or so.stat().st_mtime < (_HERE / "mc_oracle.c").stat().st_mtime:
+    srcs = [_HERE / "mc_oracle.c", _HERE / "mc_oracle.h", _HERE.parent / "include" / "mc_tables_data.h",
+            _HERE.parent / "include" / "mc_trig.h"]
+    if force or not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     return so
 
