@@ -25,8 +25,9 @@
 // member; set_indexed(true) additionally runs the reference's vertex welding on the host -- the
 // same std::set<xyz> with the same tolerance comparator fed in the same order
 // (marching.cpp:599-643, marching.h:32-55), so vertex_list / tri_list come out as the reference
-// builds them (normal_list is then empty).  Step-by-step, seed mode and constraints are outside
-// the hot path and not provided; a failed GPU call makes recalculate() return false and
+// builds them; normal_list then holds the reference's own area-weighted vertex normals (CalculateNormal,
+// Source/normal.h:3-41, also available as a free function).  Constraints are provided; step-by-step and seed
+// mode are outside the hot path and are not; a failed GPU call makes recalculate() return false and
 // last_error() non-empty instead of crashing.
 #pragma once
 #include <cmath>
@@ -47,8 +48,43 @@ namespace mc_amd {
 struct Poly_Data {
     std::vector<float> vertex_list;       // point xyz coordinates. size = 3*num_points
     std::vector<unsigned int> tri_list;   // triangle vertex indices, size = num_triangles*3
-    std::vector<float> normal_list;       // extra: unit gradient normal per vertex. size = 3*num_points
+    std::vector<float> normal_list;       // extra: unit normal per vertex, size = 3*num_points (soup: gradient of f,
+                                          // DESIGN.md N1; indexed mesh: CalculateNormal of normal.h)
 };
+
+// Source/normal.h:3-41 CalculateNormal: per indexed vertex the sum of cross(B-A, C-A) over its triangles (so
+// weighted by triangle area), normalised.  Same float operations in the same order as the glm code the
+// reference calls (cross: a.y*b.z - b.y*a.z, ...; normalize: v * (1/sqrt(dot(v,v))), dot = (x*x + y*y) + z*z);
+// a vertex used by no triangle, or with a zero sum, comes out NaN exactly as it does there.
+inline std::vector<float> CalculateNormal(const Poly_Data* pData) {
+    std::vector<float> n(pData->vertex_list.size(), 0.0f);
+    const size_t nt = pData->tri_list.size() / 3;
+    const float* v = pData->vertex_list.data();
+    for (size_t i = 0; i < nt; ++i) {
+        const unsigned i1 = pData->tri_list[3 * i], i2 = pData->tri_list[3 * i + 1], i3 = pData->tri_list[3 * i + 2];
+        volatile float bax = v[3 * i2] - v[3 * i1], bay = v[3 * i2 + 1] - v[3 * i1 + 1], baz = v[3 * i2 + 2] - v[3 * i1 + 2];
+        volatile float cax = v[3 * i3] - v[3 * i1], cay = v[3 * i3 + 1] - v[3 * i1 + 1], caz = v[3 * i3 + 2] - v[3 * i1 + 2];
+        volatile float p0 = bay * caz, p1 = cay * baz, p2 = baz * cax, p3 = caz * bax, p4 = bax * cay, p5 = cax * bay;
+        const float nx = p0 - p1, ny = p2 - p3, nz = p4 - p5;  // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
+        const unsigned idx[3] = {i1, i2, i3};
+        for (unsigned k : idx) {
+            volatile float a = nx + n[3 * k], b = ny + n[3 * k + 1], c = nz + n[3 * k + 2];  // normal + vNormal[i]
+            n[3 * k] = a;
+            n[3 * k + 1] = b;
+            n[3 * k + 2] = c;
+        }
+    }
+    for (size_t i = 0; i + 2 < n.size(); i += 3) {
+        volatile float xx = n[i] * n[i], yy = n[i + 1] * n[i + 1], zz = n[i + 2] * n[i + 2];
+        volatile float d = xx + yy;
+        d = d + zz;
+        volatile float inv = 1.0f / std::sqrt((float)d);
+        n[i] = n[i] * inv;
+        n[i + 1] = n[i + 1] * inv;
+        n[i + 2] = n[i + 2] * inv;
+    }
+    return n;
+}
 
 class Context {  // one GPU context shared by the facade objects that use it
 public:
@@ -301,6 +337,7 @@ private:
                 }
             t0 = t1;
         }
+        if (normals_) poly_data_.normal_list = CalculateNormal(&poly_data_);  // what the reference's drawer computes
         return true;
     }
 

@@ -57,6 +57,13 @@ int main(int argc, char** argv) {
         }
         printf("cells_per_axis=%d tris=%zu verts=%zu fnv_soup=%016llx f(1,2,3)=%g\n", march_maker.last_result().cells_per_axis,
                pd->tri_list.size() / 3, pd->vertex_list.size() / 3, (unsigned long long)h, evaluator.evaluate(ctx, 1, 2, 3));
+        if (const char* nf = getenv("MC_DEMO_NORMALS")) {  // dump normal_list (indexed mode: CalculateNormal of normal.h)
+            FILE* f = fopen(nf, "w");
+            if (!f) return 11;
+            for (size_t i = 0; i + 2 < pd->normal_list.size(); i += 3)
+                fprintf(f, "%.9g %.9g %.9g\n", pd->normal_list[i], pd->normal_list[i + 1], pd->normal_list[i + 2]);
+            fclose(f);
+        }
         if (ply) {  // PLY round trip through the reference's on-disk format (marching.cpp:665-854)
             if (!march_maker.save_poly_to_file(ply)) return 6;
             const size_t nv = pd->vertex_list.size(), ni = pd->tri_list.size();

@@ -86,3 +86,31 @@ def test_facade_constraint(mc):
                        env=dict(os.environ, MC_DEMO_CONSTRAINT="x > -0.5"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tris=6772 " in r.stdout and "fnv_soup=c18a9ae00b655374" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_indexed_normals_are_calculate_normal(mc, tmp_path):
+    """set_indexed(true): normal_list = the reference drawer's CalculateNormal (normal.h:3-41: area-weighted sum of
+    face normals per welded vertex, normalised), recomputed here in float32 from the saved PLY."""
+    import os
+    import numpy as np
+    ply, nrm = tmp_path / "m.ply", tmp_path / "n.txt"
+    r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "24", "0", "indexed", "1", "0", str(ply)], capture_output=True, text=True,
+                       env=dict(os.environ, MC_DEMO_NORMALS=str(nrm)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = ply.read_text().splitlines()
+    nv, nf = int(lines[2].split()[2]), int(lines[6].split()[2])
+    v = np.array([l.split() for l in lines[9:9 + nv]], dtype=np.float32)
+    f = np.array([l.split()[1:] for l in lines[9 + nv:9 + nv + nf]], dtype=np.int64)
+    got = np.loadtxt(nrm, dtype=np.float32).reshape(-1, 3)
+    assert got.shape == (nv, 3)
+    acc = np.zeros((nv, 3), np.float32)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    fn = np.cross((b - a).astype(np.float32), (c - a).astype(np.float32)).astype(np.float32)
+    for k in range(3):
+        np.add.at(acc, f[:, k], fn)
+    want = acc / np.linalg.norm(acc, axis=1, keepdims=True)
+    # the PLY stores %f (6 decimals), so the recomputation sees rounded vertices: agreement to ~1e-4, and outward
+    assert np.nanmax(np.abs(got - want)) < 2e-3
+    assert (np.sum(got * v, axis=1) > 0.9).all()          # sphere: normals point outwards, like the winding
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-6
