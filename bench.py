@@ -149,6 +149,9 @@ def main():
                     help="sphere: the headline configuration.  gyroid: BASELINE config 4, sin x cos y + sin y cos z + sin z cos x "
                          "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1)")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--slab-of", type=int, default=0,
+                    help="developer probe (single process): sweep only the middle slab of an N-way Z split, i.e. the per-rank "
+                         "work of an N-GPU run, to see the fixed per-step costs that bound strong scaling")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every sweep kernel by kernel (mc_march) instead of replaying the captured hipGraph (mc_graph_replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,6 +194,8 @@ def main():
     step = float(np.float32(2.0) / np.float32(args.grid_res))
     n1 = mc_amd.cells_per_axis(step)
     zb, ze = mc_amd.shard_layers(n1, world, rank)
+    if args.slab_of > 1 and world == 1:
+        zb, ze = mc_amd.shard_layers(n1, args.slab_of, args.slab_of // 2)
     flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
     ctx = mc_amd.Context(local_rank)
     cdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"

@@ -151,6 +151,14 @@ int mc_copy_tri_meta(mc_context *ctx, uint16_t *host, uint64_t max_tris);
  * as false) is skipped (marching.cpp:476) -- it emits no triangles and its code byte reads 0.  The reference's
  * set_constraint falls off its end without a return value on success (marching.cpp:199-200); here it is MC_OK. */
 int mc_set_constraint(mc_context *ctx, int i, const char *lhs, const char *op, float rhs);
+/* Seed mode: Marching::set_seed(x,y,z) (marching.cpp:125-137: refused outside [-1,1]^3) and seed_mode(bool) (:115-118).
+ * While it is on, a sweep keeps only the triangles of the cells the reference's walk visits (marching.cpp:42-101,
+ * :310-331): those reached from the cell containing the seed across faces that carry an intersection, never past the
+ * last cell whose centre lies inside [-1,1] (:84-86).  Differences, DESIGN.md: cells are the dense sweep's lattice cells
+ * (the reference re-derives their positions as -1 + k*step, a few ulp off), and the triangles come in sweep order, not in
+ * breadth-first order.  Whole-grid sweeps only (z_begin 0, z_end -1); not capturable by mc_graph_build. */
+int mc_set_seed(mc_context *ctx, float x, float y, float z);
+int mc_seed_mode(mc_context *ctx, int on);
 int mc_use_constraint(mc_context *ctx, int i, int use);
 
 /* marching.cpp:372-377: trip count of `for (v=-1.0f; v <= (float)(1.0+0.5*step); v += step)`. 0 if step rejected. */

@@ -44,7 +44,20 @@
 
 namespace mc_amd {
 
-// marching.h:26-30 (Step_Data, the one-cell teaching trace, is not part of the hot path)
+// marching.h:15-23: what the reference records while it works on ONE grid cell (its step-by-step teaching view).
+// The sweep never builds it; Marching::step_at(ix, iy, iz) fills one for a chosen cell.
+struct Step_Data {
+    int step_i = -2;
+    std::vector<float> corner_coords;    // coordinates of the 8 corners, size 24 (marching.cpp:471-472)
+    std::vector<float> corner_values;    // f at the 8 corners, size 8
+    std::vector<float> intersect_coord;  // intersection point per intersected edge, edge order, size 3*n
+    std::vector<int> tri_vlist;          // triangles as indices into intersect_coord's points, size 3*num_triangles
+    std::vector<int> edge_list;          // the edges that carry an intersection
+    float surf_constant = 0.0f;
+    int cube_code = 0;                   // extra: the 8-bit configuration (the reference only prints it)
+};
+
+// marching.h:26-30
 struct Poly_Data {
     std::vector<float> vertex_list;       // point xyz coordinates. size = 3*num_points
     std::vector<unsigned int> tri_list;   // triangle vertex indices, size = num_triangles*3
@@ -156,7 +169,99 @@ public:
     bool use_constraint0(bool b) { return use_constraint(0, b); }
     bool use_constraint1(bool b) { return use_constraint(1, b); }
     bool use_constraint2(bool b) { return use_constraint(2, b); }
+    // marching.cpp:115-137: seed mode keeps the surface reached from the seed's cell (mc_hip.h, mc_set_seed)
+    void seed_mode(bool b) { mc_seed_mode(ctx_.get(), b ? 1 : 0); }
+    bool set_seed(float x, float y, float z) {
+        if (mc_set_seed(ctx_.get(), x, y, z) != MC_OK) return false;
+        seed_[0] = x; seed_[1] = y; seed_[2] = z;
+        return true;
+    }
+    void get_seed(float* x, float* y, float* z) const { *x = seed_[0]; *y = seed_[1]; *z = seed_[2]; }
     void want_normals(bool b) { normals_ = b; }
+
+    // calculate_step (marching.cpp:456-595) for the cell with lattice indices (ix, iy, iz) of the current grid, as the
+    // reference's step-by-step mode shows it: f comes from the GPU (mc_eval_points), the table walk and the
+    // interpolation (marching.cpp:437-446) run here.  false: bad index, no evaluator, or a GPU error.
+    bool step_at(int ix, int iy, int iz, Step_Data* out) {
+        static const uint64_t tri_row[256] = MC_TRI_ROW_INIT;
+        static const uint8_t amb_face[256] = MC_AMB_FACE_INIT;
+        static const uint16_t face_corner[6] = MC_FACE_CORNER_INIT;
+        static const uint8_t edge_corner[12] = MC_EDGE_CORNER_INIT;
+        const int n1 = mc_cells_per_axis(grid_step_size_);
+        if (!out || !evaluator_ || ix < 0 || iy < 0 || iz < 0 || ix >= n1 || iy >= n1 || iz >= n1) return false;
+        std::vector<float> c((size_t)n1 + 1);
+        {
+            volatile float v = -1.0f;  // marching.cpp:372-377: the loop variable is advanced by float adds
+            for (int i = 0; i <= n1; ++i) {
+                c[(size_t)i] = v;
+                v = v + grid_step_size_;
+            }
+        }
+        const float x0 = c[ix], x1 = c[ix + 1], y0 = c[iy], y1 = c[iy + 1], z0 = c[iz], z1 = c[iz + 1];
+        Step_Data s;
+        s.step_i = (iz * n1 + iy) * n1 + ix + 1;
+        s.surf_constant = surface_constant_;
+        s.corner_coords = {x0, y0, z0, x1, y0, z0, x1, y1, z0, x0, y1, z0, x0, y0, z1, x1, y0, z1, x1, y1, z1, x0, y1, z1};  // :471-472
+        s.corner_values.resize(8);
+        auto eval = [&](const float* pts, size_t n, float* vals) {  // Marching::evaluate, marching.cpp:209-224
+            std::vector<float> sp(3 * n);
+            for (size_t i = 0; i < n; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    volatile float t = scale_[a] * pts[3 * i + a];
+                    sp[3 * i + a] = t;
+                }
+            if (mc_eval_points(ctx_.get(), evaluator_->equation().c_str(), sp.data(), n, vals) == MC_OK) return true;
+            error_ = mc_last_error();
+            return false;
+        };
+        if (!eval(s.corner_coords.data(), 8, s.corner_values.data())) return false;
+        const float iso = surface_constant_;
+        int code = 0;
+        for (int i = 0; i < 8; ++i)
+            if (s.corner_values[i] > iso) code |= 1 << i;  // :497-505
+        s.cube_code = code;
+        *out = s;
+        if (code == 0 || code == 255) return true;  // :508-510
+        int row = code;
+        if (amb_face[code] != 0xFF) {  // :523-549
+            volatile float m[3] = {0.0f, 0.0f, 0.0f};
+            for (int i = 0; i < 4; ++i) {
+                const int vi = (face_corner[amb_face[code]] >> (4 * i)) & 0xF;
+                for (int a = 0; a < 3; ++a) m[a] = m[a] + s.corner_coords[3 * vi + a];
+            }
+            float mid[3] = {(float)((double)m[0] / 4.0), (float)((double)m[1] / 4.0), (float)((double)m[2] / 4.0)}, mv = 0.0f;
+            if (!eval(mid, 1, &mv)) return false;
+            if (mv > iso) row = 255 - code;
+        }
+        auto interp = [&](float xs, float xe, float vs, float ve) {  // :437-446
+            volatile float q = (iso - vs) / (ve - vs);
+            volatile float v = q * (xe - xs);
+            if (std::isinf((float)v) || std::isnan((float)v)) return (float)((double)xs + 0.5 * (double)(xe - xs));
+            volatile float r = xs + v;
+            return (float)r;
+        };
+        int mapper[12];
+        for (int e = 0; e < 12; ++e) {  // :557-583
+            mapper[e] = 12;
+            const int v1 = edge_corner[e] & 0xF, v2 = edge_corner[e] >> 4;
+            if (((code >> v1) & 1) != ((code >> v2) & 1)) {
+                out->edge_list.push_back(e);
+                mapper[e] = (int)(out->intersect_coord.size() / 3);
+                for (int a = 0; a < 3; ++a)
+                    out->intersect_coord.push_back(interp(s.corner_coords[3 * v1 + a], s.corner_coords[3 * v2 + a], s.corner_values[v1],
+                                                          s.corner_values[v2]));
+            }
+        }
+        for (int k = 0; k < 15; k += 3) {  // :586-594
+            const int e1 = (int)((tri_row[row] >> (4 * k)) & 0xF), e2 = (int)((tri_row[row] >> (4 * k + 4)) & 0xF),
+                      e3 = (int)((tri_row[row] >> (4 * k + 8)) & 0xF);
+            if (e1 == 0xF) break;
+            out->tri_vlist.push_back(mapper[e1]);
+            out->tri_vlist.push_back(mapper[e2]);
+            out->tri_vlist.push_back(mapper[e3]);
+        }
+        return true;
+    }
     // true: weld vertices like the reference (marching.cpp:599-654); false (default): triangle soup
     void set_indexed(bool b) { indexed_ = b; }
 
@@ -348,6 +453,7 @@ private:
     float surface_constant_ = 0.0f;
     float scale_[3] = {1.0f, 1.0f, 1.0f};
     bool normals_ = true;
+    float seed_[3] = {0.0f, 0.0f, 0.0f};  // marching.cpp:35
     Poly_Data poly_data_;
     mc_result last_{};
     std::string error_;

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
     "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_tri_meta", "mc_cells_per_axis", "mc_graph_build",
-    "mc_graph_replay", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
+    "mc_graph_replay", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions", "mc_set_seed", "mc_seed_mode",
 ]
 
 
@@ -237,6 +237,16 @@ class Context:
         corner where `lhs op rhs` is false are skipped by the following sweeps of this context."""
         _check(lib().mc_set_constraint(self._h, i, lhs.encode(), op.encode(), C.c_float(rhs)))
         _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))
+
+    def set_seed(self, x: float, y: float, z: float):
+        """Marching::set_seed (marching.cpp:125-137)."""
+        lib().mc_set_seed.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        _check(lib().mc_set_seed(self._h, x, y, z))
+
+    def seed_mode(self, on: bool):
+        """Marching::seed_mode (marching.cpp:115-118): keep only the surface reached from the seed's cell."""
+        lib().mc_seed_mode.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().mc_seed_mode(self._h, 1 if on else 0))
 
     def use_constraint(self, i: int, use: bool):
         _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))

@@ -107,3 +107,90 @@ extern "C" __global__ __launch_bounds__(256) void mc_pack_codes(const u8* __rest
     }
 }
 
+
+
+// =============================================================== seed mode (Marching::seed_mode, marching.cpp:42-137, :310-331)
+// The reference walks breadth-first from the cell that contains the seed to the face neighbours across every face
+// that carries an intersection.  Here the dense sweep has already classified every cell, so the walk runs over the
+// code volume: frontier in, frontier out, one launch per breadth-first level; mc_seed_filter then removes the
+// triangles of unvisited cells from the records before the scan and mc_emit run.  Cell id = (z*n1 + y)*n1 + x.
+#include "../../include/mc_tables_data.h"
+
+__device__ __forceinline__ u32 seed_code(const u8* codes, const u32* tail, u64 pitch, int n1, int main_cells, int x, int y, int z) {
+    const u64 row = (u64)z * (u64)n1 + (u64)y;
+    return x < main_cells ? (u32)codes[row * pitch + (u64)x] : (tail[row] >> (8 * (x - main_cells))) & 0xFFu;
+}
+
+extern "C" __global__ __launch_bounds__(64) void mc_seed_init(u32* __restrict__ visited, u32* __restrict__ frontier, u32* __restrict__ counts,
+                                                    u32 cell) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        visited[cell >> 5] = 1u << (cell & 31u);
+        frontier[0] = cell;
+        counts[0] = 0u;
+        counts[1] = 0u;
+    }
+}
+
+// imax: the largest cell index a move may reach (marching.cpp:84-86: x0 + 0.5*step <= 1); the lower bound is index 0
+extern "C" __global__ __launch_bounds__(256) void mc_seed_expand(const u8* __restrict__ codes, const u32* __restrict__ tail, u64 pitch, int n1,
+                                                       int main_cells, int imax, u32* __restrict__ visited,
+                                                       const u32* __restrict__ fin, u32 nin, u32* __restrict__ fout,
+                                                       u32* __restrict__ nout, u32 cap) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nin) return;
+    const u32 cell = fin[i];
+    const int x = (int)(cell % (u32)n1), y = (int)((cell / (u32)n1) % (u32)n1), z = (int)(cell / ((u32)n1 * (u32)n1));
+    const u32 code = seed_code(codes, tail, pitch, n1, main_cells, x, y, z);
+    if (code == 0u || code == 255u) return;  // no surface in this cell: its edge list is empty (marching.cpp:508-510)
+    constexpr unsigned short kfc[6] = MC_FACE_CORNER_INIT;  // marching_lookup.h:25-32
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        // the face carries an intersection iff its four corners are not all on one side (marching.cpp:62-69)
+        int ones = 0, bx = 0, by = 0, bz = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = (kfc[f] >> (4 * k)) & 0xF;
+            ones += (code >> v) & 1u;
+            bx += (0x66 >> v) & 1;
+            by += (0xCC >> v) & 1;
+            bz += v >> 2;
+        }
+        if (ones == 0 || ones == 4) continue;
+        // marching_lookup.h:43-50 cube_face_normal = the axis on which the face's corners agree
+        const int nx = x + (bx == 4 ? 1 : bx == 0 ? -1 : 0), ny = y + (by == 4 ? 1 : by == 0 ? -1 : 0),
+                  nz = z + (bz == 4 ? 1 : bz == 0 ? -1 : 0);
+        if (nx < 0 || ny < 0 || nz < 0 || nx > imax || ny > imax || nz > imax) continue;  // marching.cpp:84-86
+        const u32 nc = ((u32)nz * (u32)n1 + (u32)ny) * (u32)n1 + (u32)nx;
+        const u32 bit = 1u << (nc & 31u);
+        if (!(atomicOr(&visited[nc >> 5], bit) & bit)) {  // marching.cpp:89-97: queue it unless it is in the set already
+            const u32 slot = atomicAdd(nout, 1u);
+            if (slot < cap) fout[slot] = nc;
+        }
+    }
+}
+
+// one lane per segment: records of unvisited cells lose their triangles; the segment's triangle prefix, its
+// counts and the group sums are rebuilt
+extern "C" __global__ __launch_bounds__(256) void mc_seed_filter(u32* __restrict__ recs, uint2* __restrict__ segcb, const u32* __restrict__ visited,
+                                                       u32 nseg, int nchunk, int n1, u64* __restrict__ grpsum,
+                                                       const u32* __restrict__ overflow) {
+    const u32 seg = blockIdx.x * 256u + threadIdx.x;
+    if (seg >= nseg || overflow[0] != 0u) return;
+    const uint2 cb = segcb[seg];
+    const u32 act = cb.x >> 16;
+    if (act == 0u) return;
+    const u32 rowidx = seg / (u32)nchunk, ch = seg - rowidx * (u32)nchunk;
+    const u32 rowcell = rowidx * (u32)n1 + ch * 256u;  // id of the segment's first cell (rowidx = z*n1 + y)
+    u32 tris = 0u;
+    for (u32 k = 0; k < act; ++k) {
+        u32 r = recs[cb.y + k];
+        const u32 cell = rowcell + (r & 0xFFu);
+        u32 nt = (r >> 17) & 7u;
+        if (!((visited[cell >> 5] >> (cell & 31u)) & 1u)) nt = 0u;
+        r = (r & 0x1FFFFu) | (nt << 17) | (tris << 20);
+        recs[cb.y + k] = r;
+        tris += nt;
+    }
+    segcb[seg] = make_uint2(tris | (act << 16), cb.y);
+    atomicAdd(&grpsum[seg >> 6], (u64)tris | ((u64)act << 32));
+}

@@ -438,8 +438,17 @@ static int grad_normal(orc_ctx *c, const float p[3], float h, float n[3], int *o
 }
 
 /* marching.cpp:456-595 calculate_step for one cell; appends to the layer */
+static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float y0, float y1, float z0, float z1,
+                   uint8_t *code_out);
+
 static int cell(orc_ctx *c, orc_layer *L, int want, const float *ax, int ix, int iy, int iz, uint8_t *code_out) {
-    const float x0 = ax[ix], x1 = ax[ix + 1], y0 = ax[iy], y1 = ax[iy + 1], z0 = ax[iz], z1 = ax[iz + 1];
+    return cell_at(c, L, want, ax[ix], ax[ix + 1], ax[iy], ax[iy + 1], ax[iz], ax[iz + 1], code_out);
+}
+
+/* calculate_step for the cell with lower corner (x0,y0,z0) and upper corner (x1,y1,z1): the dense sweep passes
+ * lattice coordinates, seed mode passes x0 and x0 + step (marching.cpp:458-460) */
+static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float y0, float y1, float z0, float z1,
+                   uint8_t *code_out) {
     /* :471-472 */
     const float cx[8] = {x0, x1, x1, x0, x0, x1, x1, x0};
     const float cy[8] = {y0, y0, y1, y1, y0, y0, y1, y1};
@@ -686,4 +695,59 @@ int orc_march_constrained(const char *eq, float step, float iso, const float sca
     out->fnv_codes = hc;
     out->fnv_soup = (want & ORC_WANT_SOUP) ? hs : 0;
     return 0;
+}
+
+
+/* ------------------------------------------------------------------ seed mode (marching.cpp:42-137, :310-331)
+ * The breadth-first walk itself (deque + std::set<xyz> with the tolerance comparator of marching.h:32-55) is
+ * restated in mc_oracle_seed.cpp with the same containers; this is its per-cell back end. */
+typedef struct {
+    orc_expr e;
+    orc_ctx c;
+    orc_layer L;
+    int want;
+} orc_seed_state;
+
+void *orc_seed_begin(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want) {
+    if (!((double)step >= 0.001 && (double)step <= .5)) return NULL;
+    orc_seed_state *s = (orc_seed_state *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    if (!orc_tokenize(eq, &s->e)) { free(s); return NULL; }
+    s->c.e = &s->e;
+    s->c.iso = iso;
+    s->c.step = step;
+    s->c.sx = scale[0];
+    s->c.sy = scale[1];
+    s->c.sz = scale[2];
+    s->c.ncons = 0;
+    s->want = want;
+    if (stk_init(&s->c.stk, &s->e, pow_mode)) { orc_expr_free(&s->e); free(s); return NULL; }
+    return s;
+}
+
+/* calculate_step(x0, y0, z0) + add_step_to_poly_data for one cell; *code_out = its cube code */
+int orc_seed_cell(void *h, float x0, float y0, float z0, uint8_t *code_out) {
+    orc_seed_state *s = (orc_seed_state *)h;
+    const float st = s->c.step;
+    return cell_at(&s->c, &s->L, s->want, x0, x0 + st, y0, y0 + st, z0, z0 + st, code_out); /* :458-460 */
+}
+
+void orc_seed_finish(void *h, orc_mesh *out, uint64_t n_cells) {
+    orc_seed_state *s = (orc_seed_state *)h;
+    memset(out, 0, sizeof(*out));
+    out->n1 = orc_cells_per_axis(s->c.step);
+    out->n_cells = n_cells;
+    out->n_active = s->L.n_active;
+    out->n_amb = s->L.n_amb;
+    out->n_flipped = s->L.n_flip;
+    out->n_tris = s->L.ntri;
+    out->soup = s->L.soup;
+    out->normals = s->L.nrm;
+    if ((s->want & ORC_WANT_SOUP) && !out->soup) out->soup = (float *)malloc(36);
+    if ((s->want & ORC_WANT_NORMALS) && !out->normals) out->normals = (float *)malloc(36);
+    out->fnv_soup = out->soup ? orc_fnv1a(out->soup, out->n_tris * 9 * sizeof(float), FNV_OFFSET) : FNV_OFFSET;
+    out->fnv_codes = FNV_OFFSET;
+    stk_free(&s->c.stk);
+    orc_expr_free(&s->e);
+    free(s);
 }

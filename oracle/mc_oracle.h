@@ -111,6 +111,18 @@ typedef struct {
 int orc_march_constrained(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want,
                           int z_begin, int z_end, int nthreads, const orc_constraint *cons, int ncons, orc_mesh *out);
 
+/* Seed mode (Marching::seed_mode / set_seed / the seed branch of recalculate, marching.cpp:42-137, :310-331): the mesh
+ * of the cells reached from the cell that contains `seed` by crossing faces that carry an intersection, in the
+ * reference's breadth-first order and with its float cell positions (-1 + floor(d)*step for the start, +-step per move)
+ * and its tolerance set of visited positions.  No constraints.  out->n_cells = cells visited.  Returns 0, -1 parse error,
+ * -2 evaluation underflow, -3 bad step, -5 seed outside [-1,1]^3 (set_seed refuses it, marching.cpp:125-137). */
+int orc_march_seed(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want, const float seed[3],
+                   orc_mesh *out);
+/* per-cell back end of the walk (mc_oracle_seed.cpp drives it) */
+void *orc_seed_begin(const char *eq, float step, float iso, const float scale[3], int pow_mode, int want);
+int orc_seed_cell(void *h, float x0, float y0, float z0, uint8_t *code_out);
+void orc_seed_finish(void *h, orc_mesh *out, uint64_t n_cells);
+
 /* FNV-1a 64 (offset 1469598103934665603, prime 1099511628211), SURVEY.md section 4. */
 uint64_t orc_fnv1a(const void *p, size_t n, uint64_t h);
 

@@ -46,7 +46,7 @@ class _Mesh(C.Structure):
 def build(force=False):
     """Compile liboracle.so (and _ref/check_tables where the reference exists)."""
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / "mc_oracle.c", _HERE / "mc_oracle.h", _HERE.parent / "include" / "mc_tables_data.h",
+    srcs = [_HERE / "mc_oracle.c", _HERE / "mc_oracle_seed.cpp", _HERE / "mc_oracle.h", _HERE.parent / "include" / "mc_tables_data.h",
             _HERE.parent / "include" / "mc_trig.h"]
     if force or not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -100,6 +100,30 @@ def tokens(eq: str):
         return None
     out = [(e.tok[i].type, e.tok[i].ch.decode(), e.tok[i].num) for i in range(e.n)]
     lib().orc_expr_free(C.byref(e))
+    return out
+
+
+def march_seed(eq: str, step: float, seed, iso: float = 0.0, scale=(1.0, 1.0, 1.0), pow_mode=POW_LIBM,
+               want=WANT_SOUP) -> "Mesh":
+    """Seed mode (marching.cpp:310-331): the mesh reached from the seed's cell, breadth-first order."""
+    L = lib()
+    L.orc_march_seed.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int,
+                                 C.POINTER(C.c_float), C.POINTER(_Mesh)]
+    L.orc_march_seed.restype = C.c_int
+    m = _Mesh()
+    r = L.orc_march_seed(eq.encode(), C.c_float(step), C.c_float(iso), (C.c_float * 3)(*scale), pow_mode, want,
+                         (C.c_float * 3)(*seed), C.byref(m))
+    if r:
+        raise ValueError(f"orc_march_seed failed ({r}) for {eq!r}")
+    out = Mesh()
+    for k in ("n1", "n_cells", "n_active", "n_tris", "n_amb", "n_flipped", "fnv_soup"):
+        setattr(out, k, getattr(m, k))
+    nt = m.n_tris
+    out.soup = (np.ctypeslib.as_array(m.soup, shape=(nt * 9,)).copy().reshape(nt, 3, 3) if (want & WANT_SOUP) and nt
+                else np.zeros((0, 3, 3), np.float32))
+    out.normals = (np.ctypeslib.as_array(m.normals, shape=(nt * 9,)).copy().reshape(nt, 3, 3)
+                   if (want & WANT_NORMALS) and nt else None)
+    L.orc_mesh_free(C.byref(m))
     return out
 
 

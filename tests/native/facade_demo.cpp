@@ -37,6 +37,13 @@ int main(int argc, char** argv) {
         march_maker.set_scaling_y(scale);
         march_maker.set_scaling_z(scale);
         march_maker.set_indexed(indexed);
+        if (const char* sd = getenv("MC_DEMO_SEED")) {  // "x y z": seed mode (marching.cpp:115-137)
+            float x, y, z;
+            if (sscanf(sd, "%f %f %f", &x, &y, &z) != 3) return 13;
+            if (march_maker.set_seed(2.0f, 0.0f, 0.0f)) return 14;  // outside [-1,1]: refused, the old seed stays
+            if (!march_maker.set_seed(x, y, z)) return 15;
+            march_maker.seed_mode(true);
+        }
         if (const char* c = getenv("MC_DEMO_CONSTRAINT")) {  // "lhs op rhs", the developer viewer's `x > -0.5` hotkey
             char lhs[128], op[8];
             float rhs;
@@ -57,6 +64,25 @@ int main(int argc, char** argv) {
         }
         printf("cells_per_axis=%d tris=%zu verts=%zu fnv_soup=%016llx f(1,2,3)=%g\n", march_maker.last_result().cells_per_axis,
                pd->tri_list.size() / 3, pd->vertex_list.size() / 3, (unsigned long long)h, evaluator.evaluate(ctx, 1, 2, 3));
+        if (getenv("MC_DEMO_STEPS")) {  // the one-cell teaching trace, for EVERY cell in sweep order: its triangles
+            const int n1 = march_maker.last_result().cells_per_axis;   // concatenated must be the sweep's soup
+            uint64_t hs = 1469598103934665603ull, hc = 1469598103934665603ull;
+            size_t ntri = 0;
+            Step_Data sd;
+            for (int iz = 0; iz < n1; ++iz)
+                for (int iy = 0; iy < n1; ++iy)
+                    for (int ix = 0; ix < n1; ++ix) {
+                        if (!march_maker.step_at(ix, iy, iz, &sd)) return 12;
+                        const unsigned char cb = (unsigned char)sd.cube_code;
+                        hc = (hc ^ cb) * 1099511628211ull;
+                        for (int v : sd.tri_vlist) {
+                            const unsigned char* q = reinterpret_cast<const unsigned char*>(&sd.intersect_coord[3 * (size_t)v]);
+                            for (int i = 0; i < 12; ++i) hs = (hs ^ q[i]) * 1099511628211ull;
+                        }
+                        ntri += sd.tri_vlist.size() / 3;
+                    }
+            printf("steps: tris=%zu fnv_codes=%016llx fnv_soup=%016llx\n", ntri, (unsigned long long)hc, (unsigned long long)hs);
+        }
         if (const char* nf = getenv("MC_DEMO_NORMALS")) {  // dump normal_list (indexed mode: CalculateNormal of normal.h)
             FILE* f = fopen(nf, "w");
             if (!f) return 11;

@@ -114,3 +114,36 @@ def test_facade_indexed_normals_are_calculate_normal(mc, tmp_path):
     assert np.nanmax(np.abs(got - want)) < 2e-3
     assert (np.sum(got * v, axis=1) > 0.9).all()          # sphere: normals point outwards, like the winding
     assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,iso,tris,fnv_codes,fnv_soup", [
+    ("x^2+y^2+z^2-1", 16, 0.0, None, None, None),                                     # against the sweep itself
+    ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 4, 0.0, None, "3fe2175923bab521", "4b4bd108c366fe8f"),
+    ("(x-0.1)*(y+0.07)*(z-0.13)-0.0005", 4, 0.0, None, "38924c48d8f5cae0", "ab531bb809938f33"),   # (both ambiguity outcomes)
+])
+def test_facade_step_trace_of_every_cell_rebuilds_the_sweep(mc, eq, n, iso, tris, fnv_codes, fnv_soup):
+    """Marching::step_at (the reference's step-by-step Step_Data for one cell, marching.cpp:456-595) called for every
+    cell in sweep order: the concatenated triangles are the sweep's soup and the codes its code volume, bit for bit --
+    for the two ambiguity rows that is the fingerprint SURVEY.md recorded from the unmodified reference."""
+    import os
+    r = subprocess.run([str(build_demo(mc)), eq, str(n), str(iso)], capture_output=True, text=True, env=dict(os.environ, MC_DEMO_STEPS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    sweep = [l for l in r.stdout.splitlines() if l.startswith("cells_per_axis")][0]
+    steps = [l for l in r.stdout.splitlines() if l.startswith("steps:")][0]
+    assert steps.split("tris=")[1].split()[0] == sweep.split("tris=")[1].split()[0]
+    assert steps.split("fnv_soup=")[1].split()[0] == sweep.split("fnv_soup=")[1].split()[0]
+    if fnv_soup:
+        assert f"fnv_codes={fnv_codes}" in steps and f"fnv_soup={fnv_soup}" in steps
+
+
+@pytest.mark.gpu
+def test_facade_seed_mode(mc):
+    """seed_mode(true) + set_seed(1,0,0) on the unit sphere: the count of the oracle's restatement of the reference's walk
+    (tests/test_oracle_pins.py); seed (0,0,0) sits in a cell without a crossing and yields nothing."""
+    import os
+    for seed, tris in (("1 0 0", 9537), ("0 0 0", 0)):
+        r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "32", "0"], capture_output=True, text=True,
+                           env=dict(os.environ, MC_DEMO_SEED=seed))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f" tris={tris} " in r.stdout, r.stdout

@@ -409,3 +409,100 @@ def test_largest_grid_step_0001(mc):
         assert np.abs(np.sum(v[:, :3] * v[:, 3:], axis=1) - 1).max() < 1e-4   # normals point outwards (towards f > iso)
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- seed mode (marching.cpp:42-137, :310-331)
+def _match_triangle_sets(a, b, tol):
+    """Every triangle of a has a partner in b within tol (max-norm over its 9 coordinates) and vice versa."""
+    from scipy.spatial import cKDTree
+    a, b = a.reshape(-1, 9).astype(np.float64), b.reshape(-1, 9).astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if len(a) == 0:
+        return
+    d, idx = cKDTree(b).query(a, k=1, p=np.inf)
+    assert d.max() <= tol, f"max distance {d.max()}"
+    assert len(np.unique(idx)) == len(b), "not a one-to-one match"
+
+
+@pytest.mark.parametrize("eq,n,seed,scale", [
+    (EQ["sphere"], 32, (1.0, 0.0, 0.0), (1.0, 1.0, 1.0)),        # the whole sphere except the cells the bound check excludes
+    (EQ["sphere"], 32, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),        # a seed cell without a crossing: nothing
+    ("x^2-0.25", 32, (0.5, 0.0, 0.0), (1.0, 1.0, 1.0)),          # two sheets: only the one the seed touches
+    ("x^2-0.25", 32, (-0.52, 0.3, 0.2), (1.0, 1.0, 1.0)),
+    ("x^2-0.25", 32, (-0.5, 0.3, 0.2), (1.0, 1.0, 1.0)),         # the crossing is in the cell next door: nothing
+    (EQ["eq3"], 48, (0.0, 0.33, 0.0), (1.0, 1.0, 1.0)),
+    (EQ["eq8"], 40, (0.0, 0.0, 0.6), (1.0, 1.0, 1.0)),
+    (EQ["sphere"], 40, (0.5, 0.0, 0.0), (2.0, 1.0, 1.5)),        # seed / scale picks the cell (marching.cpp:106-108)
+])
+def test_seed_mode(mc, orc, eq, n, seed, scale):
+    step = step_of(n)
+    c = mc.Context(0)
+    try:
+        c.set_seed(*seed)
+        c.seed_mode(True)
+        r = c.march(eq, step, 0.0, scale)
+        o = orc.march_seed(eq, step, seed, 0.0, scale, pow_mode=orc.POW_EXACT)
+        assert r.n_tris == o.n_tris
+        # same triangles, the reference's in breadth-first order and at cell positions -1 + k*step (ulps off the lattice)
+        _match_triangle_sets(r.vertices()[:, :, :3], o.soup, TOL_POS)
+        # the code volume is the dense sweep's: seed mode only selects triangles
+        c.seed_mode(False)
+        full = c.march(eq, step, 0.0, scale)
+        assert np.array_equal(r.codes(), full.codes()) and r.n_tris <= full.n_tris
+    finally:
+        c.close()
+
+
+def test_seed_mode_errors(mc):
+    c = mc.Context(0)
+    try:
+        with pytest.raises(mc.McError):
+            c.set_seed(1.5, 0, 0)                       # marching.cpp:128
+        c.set_seed(1, 0, 0)
+        c.seed_mode(True)
+        with pytest.raises(mc.McError):
+            c.march(EQ["sphere"], step_of(32), z_begin=0, z_end=10)     # whole grid only
+        with pytest.raises(mc.McError):
+            c.graph_build(EQ["sphere"], step_of(32))
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n,seed", [(300, (0.0, 1.0, 0.0)), (256, (0.0, 0.0, -1.0))])   # 257 cells per axis: tail plane
+def test_seed_mode_large_grids_are_exact_components(mc, orc, n, seed):
+    """Beyond ~200 cells per axis the REFERENCE's walk drifts: it re-derives cell positions by adding +-step per move in
+    float, the error passes its own 1e-6 set tolerance and cells are visited twice (the oracle, which restates it with
+    the same containers, returns 848 145 triangles at grid_res 300 where the whole dense surface has 848 100).  The
+    product walks lattice indices, so here it is checked against what the walk MEANS: the dense surface minus the cells
+    the bound check excludes (index N on any axis, marching.cpp:84-86) -- the sphere is one component."""
+    step = step_of(n)
+    c = mc.Context(0)
+    try:
+        full = c.march(EQ["sphere"], step)
+        fv = full.vertices()[:, :, :3]
+        c.set_seed(*seed)
+        c.seed_mode(True)
+        r = c.march(EQ["sphere"], step)
+        rv = r.vertices()[:, :, :3]
+        ax = np.empty(r.cells_per_axis + 1, f32)
+        v = f32(-1.0)
+        for i in range(len(ax)):
+            ax[i] = v
+            v = f32(v + f32(step))
+        last = ax[r.cells_per_axis - 1]                         # lower corner of the excluded outermost cells
+        excluded = (fv.min(axis=1) >= last).any(axis=1)         # a triangle of such a cell has all vertices beyond it
+        # the seed result is the dense list with a few triangles removed: same order, same bits
+        fk = [t.tobytes() for t in u32(fv).reshape(len(fv), -1)]
+        rk = [t.tobytes() for t in u32(rv).reshape(len(rv), -1)]
+        kept = np.zeros(len(fk), bool)
+        j = 0
+        for i, k in enumerate(fk):
+            if j < len(rk) and k == rk[j]:
+                kept[i] = True
+                j += 1
+        assert j == len(rk), "seed-mode triangles are not a sub-sequence of the dense sweep's"
+        assert 0 < (~kept).sum() <= 16 and excluded[~kept].all()   # only triangles of the excluded outermost cells went
+        o = orc.march_seed(EQ["sphere"], step, seed, pow_mode=orc.POW_EXACT)
+        assert o.n_tris >= r.n_tris                             # the drifting walk only ever adds revisits
+    finally:
+        c.close()

@@ -200,3 +200,22 @@ def test_constraints_nan_lhs_fails_and_bad_input_is_rejected(orc):
     assert not c[:, :, touches].any() and np.array_equal(c[:, :, ~touches], full[:, :, ~touches])
     with pytest.raises(ValueError):
         orc.march("x", step, constraints=[("x+a", ">", 0)])
+
+
+# ---------------------------------------------------------------- seed mode (marching.cpp:42-137, :310-331)
+def test_seed_mode_walks_one_component_and_respects_the_bound(orc):
+    step = 2.0 / 32
+    full = orc.march("x^2-0.25", step)
+    assert full.n_tris == 2 * 33 * 33 * 2                       # two sheets over 33 x 33 cells
+    one = orc.march_seed("x^2-0.25", step, (0.5, 0.0, 0.0))
+    # the walk never moves to a cell whose centre is beyond 1 (marching.cpp:84-86): 32 x 32 cells of ONE sheet
+    assert one.n_tris == 32 * 32 * 2 and one.n_cells == 32 * 32
+    assert one.soup[:, :, 0].min() > 0.49 and one.soup[:, :, 1:].max() <= 1.0
+    # a seed whose cell has no crossing produces nothing (the neighbour cell holds the crossing)
+    assert orc.march_seed("x^2-0.25", step, (-0.5, 0.3, 0.2)).n_tris == 0
+    assert orc.march_seed("x^2+y^2+z^2-1", step, (0.0, 0.0, 0.0)).n_tris == 0
+    # the sphere from a surface seed: everything but the cells of the excluded outermost layer
+    s = orc.march_seed("x^2+y^2+z^2-1", step, (1.0, 0.0, 0.0))
+    assert 0 < orc.march("x^2+y^2+z^2-1", step).n_tris - s.n_tris < 40
+    with pytest.raises(ValueError):
+        orc.march_seed("x^2+y^2+z^2-1", step, (1.5, 0.0, 0.0))   # set_seed refuses it (marching.cpp:128)
