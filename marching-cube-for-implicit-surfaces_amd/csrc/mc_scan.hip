@@ -126,22 +126,28 @@ extern "C" __global__ __launch_bounds__(64) void mc_seed_init(u32* __restrict__ 
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         visited[cell >> 5] = 1u << (cell & 31u);
         frontier[0] = cell;
-        counts[0] = 0u;
+        counts[0] = 1u;  // level 0 holds the seed's cell
         counts[1] = 0u;
+        counts[2] = 0u;
     }
 }
 
+// One breadth-first level.  The frontier sizes live on the device (counts[level % 3]) so that the host can enqueue many
+// levels without reading anything back: this launch reads counts[lvl % 3], appends to counts[(lvl+1) % 3] and zeroes
+// counts[(lvl+2) % 3] for the launch after it; a fixed grid strides over the frontier, an empty frontier costs a launch.
 // imax: the largest cell index a move may reach (marching.cpp:84-86: x0 + 0.5*step <= 1); the lower bound is index 0
 extern "C" __global__ __launch_bounds__(256) void mc_seed_expand(const u8* __restrict__ codes, const u32* __restrict__ tail, u64 pitch, int n1,
                                                        int main_cells, int imax, u32* __restrict__ visited,
-                                                       const u32* __restrict__ fin, u32 nin, u32* __restrict__ fout,
-                                                       u32* __restrict__ nout, u32 cap) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nin) return;
+                                                       const u32* __restrict__ fin, u32* __restrict__ fout,
+                                                       u32* __restrict__ counts, u32 lvl, u32 cap) {
+    const u32 nin = min(counts[lvl % 3u], cap);
+    u32* __restrict__ nout = counts + (lvl + 1u) % 3u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(lvl + 2u) % 3u] = 0u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nin; i += gridDim.x * 256u) {
     const u32 cell = fin[i];
     const int x = (int)(cell % (u32)n1), y = (int)((cell / (u32)n1) % (u32)n1), z = (int)(cell / ((u32)n1 * (u32)n1));
     const u32 code = seed_code(codes, tail, pitch, n1, main_cells, x, y, z);
-    if (code == 0u || code == 255u) return;  // no surface in this cell: its edge list is empty (marching.cpp:508-510)
+    if (code == 0u || code == 255u) continue;  // no surface in this cell: its edge list is empty (marching.cpp:508-510)
     constexpr unsigned short kfc[6] = MC_FACE_CORNER_INIT;  // marching_lookup.h:25-32
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
@@ -166,6 +172,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_seed_expand(const u8* __res
             const u32 slot = atomicAdd(nout, 1u);
             if (slot < cap) fout[slot] = nc;
         }
+    }
     }
 }
 
