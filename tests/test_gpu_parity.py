@@ -506,3 +506,50 @@ def test_seed_mode_large_grids_are_exact_components(mc, orc, n, seed):
         assert o.n_tris >= r.n_tris                             # the drifting walk only ever adds revisits
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- randomized differential test
+def _random_expr(rng, depth=0):
+    """A random string of the reference's grammar (no non-integer powers: those are tolerance-only)."""
+    r = rng.random()
+    if depth >= 3 or r < 0.25:
+        k = rng.random()
+        if k < 0.55:
+            return "xyz"[rng.integers(3)]
+        if k < 0.8:
+            return f"{rng.uniform(0.05, 2.5):.3g}"
+        return f"{rng.integers(1, 4)}" + "xyz"[rng.integers(3)]           # implicit multiplication, evaluator.cpp:215-223
+    if r < 0.45:
+        return _random_expr(rng, depth + 1) + "+-"[rng.integers(2)] + _random_expr(rng, depth + 1)
+    if r < 0.62:
+        return _random_expr(rng, depth + 1) + "*" + _random_expr(rng, depth + 1)
+    if r < 0.72:
+        return "(" + _random_expr(rng, depth + 1) + ")/(" + _random_expr(rng, depth + 1) + ")"
+    if r < 0.86:
+        return "(" + _random_expr(rng, depth + 1) + ")^" + str([2, 2, 3, 4, -1, -2][rng.integers(6)])
+    if r < 0.93:
+        return "-(" + _random_expr(rng, depth + 1) + ")"
+    return "(" + _random_expr(rng, depth + 1) + ")"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_expressions_match_the_oracle(mc, orc, seed):
+    """Differential test over random equations, steps, iso values and scales: interval codegen, sampling fallback,
+    NaN / inf fields, the precedence quirks -- cube codes and vertices bit for bit against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    eq = _random_expr(rng) + "-" + f"{rng.uniform(0.05, 1.0):.3g}"
+    if mc.expr_validate(eq) != 0:
+        pytest.skip("generated string is refused (evaluation underflow)")
+    n = int(rng.integers(5, 44))
+    step = step_of(n)
+    iso = float(f32(rng.uniform(-0.4, 0.4)))
+    scale = tuple(float(f32(v)) for v in rng.uniform(0.6, 1.8, 3)) if rng.random() < 0.5 else (1.0, 1.0, 1.0)
+    c = mc.Context(0)
+    try:
+        r = c.march(eq, step, iso, scale)
+        o = orc.march(eq, step, iso, scale, pow_mode=orc.POW_EXACT, want=3)
+        assert np.array_equal(r.codes(), o.codes), eq
+        assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active), eq
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, eq)
+    finally:
+        c.close()
