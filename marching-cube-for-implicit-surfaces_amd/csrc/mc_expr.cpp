@@ -359,7 +359,8 @@ std::string emit_hip(const Program& p, const char* fname) {
             if (n.ipow == 2) rhs = name(n.a) + " * " + name(n.a);
             else {
                 std::snprintf(buf, sizeof buf, "mc_pow_int<%d>(", n.ipow);
-                rhs = buf + name(n.a) + ")";
+                const std::string call = buf;  // name() reuses buf: copy before calling it
+                rhs = call + name(n.a) + ")";
             }
             break;
         }

@@ -125,3 +125,14 @@ def test_cells_per_axis_matches_oracle(mc, orc, step):
 @pytest.mark.parametrize("step", [0.0005, 0.6, 0.0, -1.0, float("nan")])
 def test_step_out_of_range(mc, step):  # marching.cpp:226-238
     assert mc.cells_per_axis(step) == 0
+
+
+def test_integer_power_of_a_subexpression_generates_valid_code(mc):
+    """(expr)^n with n not in {0, 1, 2}: the generated call must name its operand (a shared format buffer once
+    produced `t2t2)`); the kernels must compile (hiprtc runs without a GPU)."""
+    for eq in ["(x+y)^3-1", "((z)^3)^3-0.56", "(((y)/(z))^-1)^4-0.749", "0.712-1x+(2x)^3*(0.913*y)-0.885", "z+(x*y)^-2"]:
+        src = mc.expr_dump(eq)
+        assert "mc_pow_int<" in src and "t2t2" not in src
+        import re
+        assert not re.search(r"= t\d+t\d+\)", src), src
+        assert mc.jit_precompile(eq) > 0

@@ -553,3 +553,29 @@ def test_random_expressions_match_the_oracle(mc, orc, seed):
         assert_same_floats(r.vertices()[:, :, :3], o.soup, eq)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_constraints_match_the_oracle(mc, orc, seed):
+    rng = np.random.default_rng(5000 + seed)
+    eq = ["x^2+y^2+z^2-0.8", EQ["eq3"], "x*y*z-0.02", "x^2-y*z-0.1"][rng.integers(4)]
+    cons = []
+    for _ in range(int(rng.integers(1, 4))):
+        lhs = _random_expr(rng, 1)
+        if mc.expr_validate(lhs) != 0:
+            continue
+        cons.append((lhs, [">=", "<=", ">", "<"][rng.integers(4)], float(f32(rng.uniform(-0.5, 0.5)))))
+    if not cons:
+        pytest.skip("no usable constraint generated")
+    step = step_of(int(rng.integers(6, 40)))
+    c = mc.Context(0)
+    try:
+        for i, (lhs, op, rhs) in enumerate(cons):
+            c.set_constraint(i, lhs, op, rhs)
+        r = c.march(eq, step)
+        o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=3, constraints=cons)
+        assert np.array_equal(r.codes(), o.codes), (eq, cons)
+        assert r.n_tris == o.n_tris, (eq, cons)
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, str((eq, cons)))
+    finally:
+        c.close()

@@ -166,3 +166,28 @@ def test_gyroid_512_slabs_and_properties(mc, ext):
         assert np.abs(np.linalg.norm(v[:, 3:], axis=1) - 1).max() < 1e-5
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trig_expressions_match_the_oracle(mc, orc, ext, seed):
+    rng = np.random.default_rng(7000 + seed)
+    terms = []
+    for _ in range(int(rng.integers(1, 4))):
+        fn = ["sin", "cos"][rng.integers(2)]
+        arg = f"{rng.integers(1, 7)}" + "xyz"[rng.integers(3)] + ["", "+0.3", "*y", "-z"][rng.integers(4)]
+        terms.append(f"{fn}({arg})" + ["", "*x", "^2", "*cos(2z)"][rng.integers(4)])
+    eq = "+".join(terms) + "-" + f"{rng.uniform(0.05, 0.6):.3g}" + ["", "+z", "-y*y"][rng.integers(3)]
+    assert mc.expr_validate(eq) == 0, eq
+    step = float(f32(2.0) / f32(int(rng.integers(8, 48))))
+    scale = (float(f32(rng.uniform(0.7, 3.0))),) * 3
+    c = mc.Context(0)
+    try:
+        r = c.march(eq, step, 0.0, scale)
+        o = orc.march(eq, step, 0.0, scale, pow_mode=orc.POW_EXACT, want=3)
+        assert np.array_equal(r.codes(), o.codes), eq
+        assert r.n_tris == o.n_tris, eq
+        v = r.vertices()[:, :, :3]
+        assert ((_u32(v) == _u32(o.soup)) | (np.isnan(v) & np.isnan(o.soup))).all(), eq
+    finally:
+        c.close()
