@@ -4,6 +4,8 @@ Bar: cube codes bit-exact; triangle soup bit-exact against the oracle in exact-p
 (which is far inside the north star's 1e-5) and within 1e-5 of the libm-powf (reference)
 vectors; normals within 1e-6 of the oracle's N1 definition.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -532,7 +534,7 @@ def _random_expr(rng, depth=0):
     return "(" + _random_expr(rng, depth + 1) + ")"
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_SEEDS", "48"))))
 def test_random_expressions_match_the_oracle(mc, orc, seed):
     """Differential test over random equations, steps, iso values and scales: interval codegen, sampling fallback,
     NaN / inf fields, the precedence quirks -- cube codes and vertices bit for bit against the oracle."""
@@ -555,7 +557,7 @@ def test_random_expressions_match_the_oracle(mc, orc, seed):
         c.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_SEEDS", "16"))))
 def test_random_constraints_match_the_oracle(mc, orc, seed):
     rng = np.random.default_rng(5000 + seed)
     eq = ["x^2+y^2+z^2-0.8", EQ["eq3"], "x*y*z-0.02", "x^2-y*z-0.1"][rng.integers(4)]
