@@ -581,3 +581,28 @@ def test_random_constraints_match_the_oracle(mc, orc, seed):
         assert_same_floats(r.vertices()[:, :, :3], o.soup, str((eq, cons)))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_LARGE", "6"))))
+def test_random_equations_on_multi_chunk_grids(mc, orc, seed):
+    """Random equations on grids around the 256-cell chunk boundary (ragged last chunk, tail plane for 1..4 cells,
+    several chunks) and random Z slabs: bit for bit against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    eq = _random_expr(rng) + "-" + f"{rng.uniform(0.05, 1.0):.3g}"
+    if mc.expr_validate(eq) != 0:
+        pytest.skip("generated string is refused (evaluation underflow)")
+    n = int([255, 256, 257, 258, 259, 260, 300, 383, 511, 512][rng.integers(10)])
+    step = step_of(n)
+    n1 = mc.cells_per_axis(step)
+    zb = int(rng.integers(0, n1 - 8))
+    ze = int(min(n1, zb + rng.integers(4, 40)))
+    iso = float(f32(rng.uniform(-0.3, 0.3)))
+    c = mc.Context(0)
+    try:
+        r = c.march(eq, step, iso, z_begin=zb, z_end=ze)
+        o = orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=3, z_begin=zb, z_end=ze)
+        assert np.array_equal(r.codes(), o.codes), (eq, n, zb, ze)
+        assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active), (eq, n, zb, ze)
+        assert_same_floats(r.vertices()[:, :, :3], o.soup, str((eq, n, zb, ze)))
+    finally:
+        c.close()
