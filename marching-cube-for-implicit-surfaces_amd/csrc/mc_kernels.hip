@@ -260,25 +260,29 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY 
 }
 
 // =============================================================== K1: classify
-// One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer,
-// walked along y for up to 63 rows.  Every lattice sample of the two z planes is evaluated
-// once per tile row and the previous row's samples stay in registers, so a cell costs 2
-// evaluations instead of 8.  The kernel is bound by instruction issue, not by HBM (measured,
-// profiles/: a VOP3 op such as v_cmp->SGPR, v_max3 or v_addc costs ~4 cycles per wave on its
-// SIMD, a VOP2 add ~2.2, and scalar ops are not free either), so the design minimises
-// instructions per 256-cell step:
+// One wave = one tile: a 256-cell x-chunk (4 consecutive cells per lane) of one z layer, up to 63 rows high
+// (or, for the 1..4-cell last chunk of a 2^k+1 grid, 64 rows with one ROW per lane: "tail tiles").
 //
-//  * Uniform steps (every corner of all 256 cells on one side of iso -- ~70 % of the steps
-//    of the 1024^3 sphere) are recognised with a min/max tree over the lane's 8 new samples
-//    and two v_cmp, and store 0x00000000 / 0xFFFFFFFF: ~20 VALU + ~10 SALU ops.
-//  * Mixed steps classify each LANE the same way with four more v_cmp (the lane's "x+4"
-//    neighbour column) and a little mask algebra: lanes whose 4 cells are all-below /
-//    all-above store 0 / ~0; the few remaining lanes (1-4 per step on a smooth surface) only
-//    note their position in a per-wave LDS list.
-//  * The expensive part -- assembling the 8-bit cube codes of those lanes, triangle-count
-//    lookup, ambiguity test, per-segment prefix sums and the compact per-cell RECORDS the
-//    emit kernel consumes -- runs lane-parallel over that list once per tile (a tile has ~35
-//    listed lanes on a smooth surface) instead of wave-wide in each of its ~20 mixed steps.
+//  1. Row test, lane = row: one interval evaluation (mc_f_iv, generated from the same DAG as mc_f) over the box
+//     of each row proves most rows all-above / all-below iso without evaluating a sample.
+//  2. The rows are handled class by class (set-bit iteration over 64-bit masks: the CU has ONE scalar unit and a
+//     per-row decision tree cost more scalar instructions than the work): aligned blocks of 4 proven rows ->
+//     one dwordx4 store per lane; other proven rows -> one dword store; undecided rows -> one more interval
+//     evaluation per LANE (its 4 cells), giving the lanes proven all-above and the lanes still undecided
+//     ("listed"); those two masks are parked in lane `row` of four VGPRs (v_writelane).
+//  3. Back-end (mc_backend), lane-parallel over the listed dwords: exact evaluation of the 20 lattice samples of
+//     each, cube codes, triangle counts (LDS LUT), ambiguity test, per-segment prefix sums, one RECORD per active
+//     cell (buffered in LDS, appended to the dense record array with one scalar atomic per tile), and the
+//     undecided code rows written whole.
+//
+// Equations whose values cannot be bounded (possible NaN / inf: the host decides, finite_on_domain) take the
+// sampling walk instead of 1-2: the previous row's samples stay in registers (2 evaluations per cell) and rows /
+// lanes are classified by a min/max tree over the lane's 8 new samples; the back-end is the same.
+//
+// What bounds it (measured): the 1.26 GB of stores at ~5 TB/s, with the instruction stream
+// (89 M vector + 69 M scalar wave-instructions per 1025^3 sweep) just below that.  Hence the rules kept throughout:
+// no global LOAD after the first store (vmcnt retires in order: a load would wait for every store in flight),
+// whole 128-byte lines only, wave-uniform work on the scalar unit only where it is cheaper than on the VALU.
 #ifndef MC_CLASSIFY_MINW
 #define MC_CLASSIFY_MINW 1
 #endif
