@@ -372,15 +372,21 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             // SCALAR atomic: its result comes back through lgkmcnt.  A vector atomic's would come through
             // vmcnt, which retires in order -- the wave would sit until every code store it has in flight had
             // landed before it could even start copying its records (measured: 0.36 -> 0.44 ms).
-            u32 gb;
-            {
+#ifdef MC_DBG_NO_FLUSH  // timing probe only (wrong results): no allocation, no copy
+            const bool probe_skip = true;
+#else
+            const bool probe_skip = false;
+#endif
+            u32 gb = 0u;
+            if (!probe_skip) {
                 u32* const cur = p.rec_cursor + 32u * (1u + t.region);
                 asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(gb) : "s"(cur), "0"(nbuf) : "memory");
             }
             const u32 rsize = (u32)(p.cap_recs / MC_NCUR);
             // past the region's end nothing is written and the overflow word is raised: the host grows the
             // buffer and sweeps again; mc_emit sees the word and stays out
-            if (gb + nbuf <= rsize) {
+            if (probe_skip) {
+            } else if (gb + nbuf <= rsize) {
                 gb += t.region * rsize;
                 for (u32 i = (u32)t.lane; i < nbuf; i += 64u) recs[gb + i] = recbuf[i];
             } else if (t.lane == 0) {
@@ -400,6 +406,8 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
         const u32 e1 = (u32)__builtin_amdgcn_readlane((int)incl, jl);
         const u32 ntake = e1 - e0;
         u32 dw = 0;
+        int ej = 0, eln = 0;   // this entry lane's row and chunk lane
+        bool evalid = false;
         if (ntake) {
             if (nbuf + 256u > MC_REC_CAP) flush_records();  // a chunk adds at most 64 * 4 records
             marker[t.lane] = 0u;
@@ -456,6 +464,9 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
                 if (x0 + c < n1) dw |= code << (8 * c);
             }
             if (!valid) dw = 0u;
+            ej = jj;
+            eln = ln;
+            evalid = valid;
 
             // per cell: triangle count and ambiguity flip; meta nibble c = count | flip<<3
             u32 meta = 0, packed = 0;  // packed = triangles | active cells << 16 of this entry
@@ -506,28 +517,43 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             nbuf += (u32)__builtin_amdgcn_readlane((int)pincl, 63) >> 16;
         }
         epochRows |= fit;
+#ifdef MC_DBG_NO_ROWLOOP  // timing probe only (wrong results)
+        if (false) {
+#else
         if (!TAIL) {
-            // the pending code rows this chunk completes, each written WHOLE (256 B, full 128-byte lines):
-            // the listed lanes' dwords come from the entry lanes (ds_bpermute), the others are 0 / ~0 by the
-            // walk's per-lane masks.  (Writing only the listed dwords here and the rest in the walk made
-            // every such line a partial write -- a read-modify-write in HBM; measured.)
+#endif
+            // The pending code rows this chunk completes.  Each row is stored WHOLE (256 B, full 128-byte lines) with
+            // what the walk proved -- lanes all-above as ~0, the others, listed ones included, as 0 -- and then the
+            // entry lanes overwrite their own dwords with ONE scattered store for the whole chunk: same wave, same
+            // addresses, issued right behind, so the line is still being assembled in L2 when the dwords arrive.
+            // (Measured: 0.264 ms against 0.283 for gathering each row's listed dwords with ds_bpermute before its
+            // store; but 0.296 when the rows were stored by the walk, microseconds earlier -- by then a line may have
+            // left L2 and the late dword becomes a read-modify-write in HBM.)
             u64 f = fit;
             while (f) {
                 const int jr = __builtin_ctzll(f);
                 f &= f - 1ull;
-                const u64 mix = ((u64)(u32)__builtin_amdgcn_readlane((int)rm.mixhi, jr) << 32) | (u32)__builtin_amdgcn_readlane((int)rm.mixlo, jr);
                 const u64 all = ((u64)(u32)__builtin_amdgcn_readlane((int)rm.allhi, jr) << 32) | (u32)__builtin_amdgcn_readlane((int)rm.alllo, jr);
-                const int first = (int)((u32)__builtin_amdgcn_readlane((int)off, jr) - e0);  // chunk lane of the row's first entry
-                // row lane L is listed iff bit L of mix; its entry sits at chunk lane first + rank(L)
-                const u32 mine = (u32)__shfl((int)dw, first + (int)mask_rank(mix), 64);
-                const u32 v = select_by_mask(mix, mine, select_by_mask(all, vmask_row, 0u));
-#ifndef MC_DBG_NO_STORE
+                const u32 v = select_by_mask(all, vmask_row, 0u);
+#if !defined(MC_DBG_NO_STORE) && !defined(MC_DBG_NO_ROWSTORE)
                 __builtin_amdgcn_raw_buffer_store_b32(
                     v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)jr * (u32)p.pitch), 0, (int)p.pitch, 0x00020000), (u32)xl0, 0, 0);
 #else
                 asm volatile("" ::"v"(v));
 #endif
             }
+#if !defined(MC_DBG_NO_STORE) && !defined(MC_DBG_NO_ROWSTORE)
+            // (a listed lane beyond the end of the grid -- ragged last chunk, degenerate clamped cells -- has dw == 0 and
+            // must not write: its offset lies past the row, in the rows that follow)
+            // A buffer store like the row stores above, so that both travel the same queue in issue order; lanes that
+            // must not write get an offset the range check rejects.
+            {
+                const bool wr = evalid && t.ch * MC_SEG + eln * 4 < n1;
+                const u32 eoff = wr ? (u32)ej * (u32)p.pitch + (u32)(t.ch * MC_SEG + eln * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(dw, __builtin_amdgcn_make_buffer_rsrc(tilebase, 0, (int)(64u * (u32)p.pitch), 0x00020000),
+                                                      eoff, 0, 0);
+            }
+#endif
         }
         pend &= ~fit;
         e0 = e1;
@@ -944,6 +970,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // general powers, possible NaN / inf)
     // lower (r0) / upper (r1) sample rows, plane z (a) and plane z+1 (c).  Written as straight
     // code: as lambdas the closure did not get scalarised and lived in scratch memory.
+    const u64 lanesInS = __ballot(x0 < n1);  // lanes that hold cells of the grid
     float r0a[4], r0c[4], r1a[4], r1c[4];
     u64 gtPrev = 0, gePrev = 0;  // lower row, per lane: some sample > iso / every sample > iso
     bool haveLower = false;      // the lower sample row of the next step is in r0a / r0c
@@ -1018,7 +1045,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             const u64 nbAll = ((n0 & n1m & n2 & n3) >> 1) | topAll;
 #endif
             const u64 laneAll = allOwn & nbAll;
-            const u64 mixedL = (anyOwn | nbAny) & ~laneAll;  // lanes with corners on both sides of iso
+            const u64 mixedL = (anyOwn | nbAny) & ~laneAll & lanesInS;  // lanes with corners on both sides of iso
             if (mixedL) {  // the back-end writes this row whole
                 MC_SET_ROW(j, mixedL, laneAll)
                 rowPend |= 1ull << j;
