@@ -47,3 +47,21 @@ def test_product_does_not_link_oracle(mc):
     assert "oracle" not in out
     syms = subprocess.run(["nm", "-D", str(mc.LIB_PATH)], capture_output=True, text=True).stdout
     assert "orc_" not in syms
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mc_hip.h must be usable from C (the boundary is a C ABI): compile a C99 translation unit that uses every
+    struct and calls every entry point's prototype, syntax only."""
+    import subprocess
+    from conftest import ROOT
+    src = tmp_path / "use.c"
+    src.write_text('#include "mc_hip.h"\n'
+                   'int use(mc_context *c) {\n'
+                   '    mc_params p = {"x+y", 0.25f, 0.0f, {1.0f, 1.0f, 1.0f}, MC_FLAG_NORMALS, 0, -1};\n'
+                   '    mc_result r;\n'
+                   '    mc_set_constraint(c, 0, "x", ">", -0.5f); mc_use_constraint(c, 0, 1); mc_set_seed(c, 0, 0, 0); mc_seed_mode(c, 0);\n'
+                   '    return mc_march(c, &p, &r) + (int)r.n_tris + mc_abi_version();\n'
+                   '}\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", f"-I{ROOT / 'include'}", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
