@@ -52,8 +52,33 @@ ROWS = [
 ]
 
 
+# "next" rows of the path: no reference fingerprint exists for these, the oracle's restatement is the source
+# (parity unpinned by reference outputs).  name, equation, step, constraints, seed
+EXTRA = [
+    ("constraint_sphere_n32", "x^2+y^2+z^2-1", step_of(32), [("x", ">", -0.5)], None),          # the developer viewer's hotkey
+    ("constraint3_eq3_n32", EQ3, step_of(32), [("x", ">", -0.5), ("y+z", "<=", 0.25), ("x*y", ">=", -0.1)], None),
+    ("seed_planes_n32", "x^2-0.25", step_of(32), [], (0.5, 0.0, 0.0)),
+    ("seed_sphere_n32", "x^2+y^2+z^2-1", step_of(32), [], (1.0, 0.0, 0.0)),
+]
+
+
+def extra(out_dir):
+    for name, eq, step, cons, seed in EXTRA:
+        if seed is None:
+            m = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=orc.WANT_CODES | orc.WANT_SOUP, constraints=cons)
+            codes = m.codes
+        else:
+            m = orc.march_seed(eq, step, seed, pow_mode=orc.POW_EXACT)
+            codes = np.zeros(0, np.uint8)
+        np.savez_compressed(out_dir / f"{name}.npz", equation=np.array(eq), step=f32(step), kind=np.array("seed" if seed else "constraint"),
+                            constraints=np.array([f"{l}|{o}|{r!r}" for l, o, r in cons]), seed=np.array(seed if seed else (0, 0, 0), f32),
+                            codes=codes, soup=m.soup, n_tris=np.int64(m.n_tris))
+        print(f"{name:22s} tris={m.n_tris:6d}")
+
+
 def main():
     out_dir = Path(__file__).resolve().parent
+    extra(out_dir)
     for name, eq, step, iso, scale, ref in ROWS:
         m = orc.march(eq, step, iso, scale, pow_mode=orc.POW_LIBM, want=orc.WANT_CODES | orc.WANT_SOUP)
         e = orc.march(eq, step, iso, scale, pow_mode=orc.POW_EXACT,

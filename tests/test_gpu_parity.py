@@ -49,7 +49,32 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
 
 
 # ---------------------------------------------------------------- golden vectors
-@pytest.mark.parametrize("path", sorted(GOLDEN.glob("*.npz")), ids=lambda p: p.stem)
+@pytest.mark.parametrize("path", sorted(p for p in GOLDEN.glob("*.npz") if p.stem.split("_")[0] in ("constraint", "constraint3", "seed")),
+                         ids=lambda p: p.stem)
+def test_golden_constraints_and_seed(mc, path):
+    """Committed vectors for the 'next' rows (oracle-generated; no reference fingerprint exists for them)."""
+    g = np.load(path)
+    c = mc.Context(0)
+    try:
+        if str(g["kind"]) == "constraint":
+            for i, row in enumerate(g["constraints"]):
+                lhs, op, rhs = str(row).split("|")
+                c.set_constraint(i, lhs, op, float(rhs))
+            r = c.march(str(g["equation"]), float(g["step"]))
+            assert np.array_equal(r.codes(), g["codes"]) and r.n_tris == int(g["n_tris"])
+            assert_same_floats(r.vertices()[:, :, :3], g["soup"], "positions")
+        else:
+            c.set_seed(*[float(v) for v in g["seed"]])
+            c.seed_mode(True)
+            r = c.march(str(g["equation"]), float(g["step"]))
+            assert r.n_tris == int(g["n_tris"])
+            _match_triangle_sets(r.vertices()[:, :, :3], g["soup"], TOL_POS)   # the reference's order is breadth-first
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("path", sorted(p for p in GOLDEN.glob("*.npz") if p.stem.split("_")[0] not in ("constraint", "constraint3", "seed")),
+                         ids=lambda p: p.stem)
 def test_golden(mc, ctx, path):
     g = np.load(path)
     r = ctx.march(str(g["equation"]), float(g["step"]), float(g["iso"]), tuple(float(s) for s in g["scale"]))
