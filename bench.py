@@ -149,6 +149,8 @@ def main():
                     help="sphere: the headline configuration.  gyroid: BASELINE config 4, sin x cos y + sin y cos z + sin z cos x "
                          "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1)")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: keep the equal-height Z slabs instead of re-cutting them by measured cost before the timed steps")
     ap.add_argument("--slab-of", type=int, default=0,
                     help="developer probe (single process): sweep only the middle slab of an N-way Z split, i.e. the per-rank "
                          "work of an N-GPU run, to see the fixed per-step costs that bound strong scaling")
@@ -209,6 +211,19 @@ def main():
     mine_dev = torch.zeros(nslots, dtype=torch.int64, device=cdev) if world > 1 else None
     pending = []
     step_no = [0]
+
+    # Count-balanced Z repartition (untimed): equal-height slabs do not cost the same -- an equatorial slab of the
+    # sphere has ~1.3x the undecided rows of the average one -- so each rank times its slab, the times are gathered,
+    # and every rank re-cuts the layers so that the cumulative measured cost splits evenly (3 rounds).
+    bounds = [mc_amd.shard_layers(n1, world, r)[0] for r in range(world)] + [n1]
+    if world > 1 and not args.no_balance:
+        tdev = torch.zeros(world, dtype=torch.float64, device=cdev)
+        for _ in range(3):
+            ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+            rr = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+            dist.all_gather_into_tensor(tdev, torch.tensor([rr.ms_total], dtype=torch.float64, device=cdev))
+            bounds = mc_amd.rebalance_layers(bounds, tdev.cpu().tolist())
+            zb, ze = bounds[rank], bounds[rank + 1]
 
     # steady state: the sweep (parameter upload, classify, scan x3, emit, totals download) is captured once as a
     # hipGraph and replayed per step -- one launch instead of a dozen API calls (~30 us of host time per sweep)
@@ -288,7 +303,8 @@ def main():
                                    f"({n1}^3 cells), iso 0, scale {scale[0]:g}, normals {'off' if args.no_normals else 'on'}",
                        "cells": int(cells), "triangles": int(tris),
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
-                       "launch": "kernel by kernel" if args.no_graph else "hipGraph replay"},
+                       "launch": "kernel by kernel" if args.no_graph else "hipGraph replay",
+                       "z_bounds": bounds if world > 1 else None},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
                           "gpu_total": round(ms_tot, 4)},

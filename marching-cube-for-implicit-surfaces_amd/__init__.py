@@ -279,6 +279,40 @@ def shard_layers(n_layers: int, world: int, rank: int):
     return b, b + base + (1 if rank < rem else 0)
 
 
+def rebalance_layers(bounds, costs):
+    """Count-balanced Z repartition (host logic only).  `bounds` (world+1 ascending layer indices) are the slabs just
+    swept, `costs[i]` what slab i cost (e.g. its GPU milliseconds).  Treating the cost as spread evenly over a slab's
+    layers, returns new bounds that cut the cumulative cost into equal parts; every slab keeps at least one layer.
+    Deterministic: every rank computes the same answer from the same gathered costs."""
+    world = len(bounds) - 1
+    n = bounds[-1] - bounds[0]
+    if world <= 1 or n < world:
+        return list(bounds)
+    dens = [float(c) / max(1, bounds[i + 1] - bounds[i]) for i, c in enumerate(costs)]
+    total = sum(d * (bounds[i + 1] - bounds[i]) for i, d in enumerate(dens))
+    if not total > 0:
+        return list(bounds)
+    new = [bounds[0]]
+    acc, slab = 0.0, 0
+    z = bounds[0]
+    for k in range(1, world):
+        target = total * k / world
+        while slab < world and acc + dens[slab] * (bounds[slab + 1] - z) < target:
+            acc += dens[slab] * (bounds[slab + 1] - z)
+            slab += 1
+            z = bounds[slab] if slab < world else bounds[-1]
+        if slab >= world:
+            cut = bounds[-1]
+        else:
+            step_layers = (target - acc) / dens[slab] if dens[slab] > 0 else 0.0
+            cut = int(round(z + step_layers))
+        cut = max(cut, new[-1] + 1)                       # at least one layer per slab
+        cut = min(cut, bounds[-1] - (world - k))          # ... for the slabs still to come as well
+        new.append(cut)
+    new.append(bounds[-1])
+    return new
+
+
 def exclusive_offsets(counts):
     """Per-rank triangle offsets from the all-gathered per-rank counts."""
     out, acc = [], 0

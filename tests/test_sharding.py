@@ -76,3 +76,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["scaling"] == "strong" and d["value"] > 0
     # the halo plane a sampled-field design would exchange equals the plane each rank recomputes
     assert d["halo"]["recomputed_plane_identical_to_exchanged"] is True
+
+
+def test_rebalance_layers_equalises_a_known_cost_profile():
+    """Count-balanced Z repartition (host logic): with a per-layer cost like the sphere's undecided rows (~ sqrt(1 - z^2))
+    plus a constant, three rounds of 'measure slabs, re-cut' bring the slab costs within a few percent of each other."""
+    import numpy as np
+    import mc_amd
+    n1, world = 1025, 8
+    z = (np.arange(n1) + 0.5) / n1 * 2 - 1
+    w = 0.3 + np.sqrt(np.clip(1 - z * z, 0, None))                  # cost per layer
+    bounds = [mc_amd.shard_layers(n1, world, r)[0] for r in range(world)] + [n1]
+    spread0 = None
+    for _ in range(3):
+        costs = [float(w[bounds[i]:bounds[i + 1]].sum()) for i in range(world)]
+        spread0 = spread0 or max(costs) / (sum(costs) / world)
+        bounds = mc_amd.rebalance_layers(bounds, costs)
+        assert bounds[0] == 0 and bounds[-1] == n1 and all(b > a for a, b in zip(bounds, bounds[1:]))
+    costs = [float(w[bounds[i]:bounds[i + 1]].sum()) for i in range(world)]
+    assert spread0 > 1.15 and max(costs) / (sum(costs) / world) < 1.04
+    # degenerate inputs: nothing to balance, or fewer layers than ranks
+    assert mc_amd.rebalance_layers([0, 5, 10], [0.0, 0.0]) == [0, 5, 10]
+    assert mc_amd.rebalance_layers([0, 1, 2, 3], [5.0, 1.0, 1.0]) == [0, 1, 2, 3]
