@@ -26,8 +26,10 @@
 // same std::set<xyz> with the same tolerance comparator fed in the same order
 // (marching.cpp:599-643, marching.h:32-55), so vertex_list / tri_list come out as the reference
 // builds them; normal_list then holds the reference's own area-weighted vertex normals (CalculateNormal,
-// Source/normal.h:3-41, also available as a free function).  Constraints are provided; step-by-step and seed
-// mode are outside the hot path and are not; a failed GPU call makes recalculate() return false and
+// Source/normal.h:3-41, also available as a free function).  Constraints (set_constraint0..2 / use_constraint0..2)
+// and seed mode (seed_mode / set_seed) are provided -- seed mode returns the same triangles as the reference's
+// walk, in sweep order (mc_hip.h).  The step-by-step STATE MACHINE of recalculate() is not; step_at(ix, iy, iz)
+// gives the Step_Data of any one cell instead.  A failed GPU call makes recalculate() return false and
 // last_error() non-empty instead of crashing.
 #pragma once
 #include <cmath>
