@@ -149,6 +149,10 @@ def main():
                     help="sphere: the headline configuration.  gyroid: BASELINE config 4, sin x cos y + sin y cos z + sin z cos x "
                          "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1)")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--halo-check", action="store_true",
+                    help="N > 1, outside the timed region: exchange the boundary sample plane with the Z neighbour (send/recv) and "
+                         "compare it with the plane this rank recomputes -- the halo a sampled-field design would need (opt-in: "
+                         "a diagnostic must not be able to stall the scaling measurement)")
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1: keep the equal-height Z slabs instead of re-cutting them by measured cost before the timed steps")
     ap.add_argument("--slab-of", type=int, default=0,
@@ -252,7 +256,7 @@ def main():
         torch.cuda.synchronize()
 
     halo = None
-    if world > 1:
+    if world > 1 and args.halo_check:
         try:  # a diagnostic outside the timed region: never let it take the measurement down
             halo = halo_check(ctx, mc_amd, torch, dist, eq, step, n1, zb, ze, rank, world, scale[0])
         except Exception as e:  # noqa: BLE001

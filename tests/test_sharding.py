@@ -68,12 +68,14 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", "29534", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
-                        "1", "--grid-res", "256"], capture_output=True, text=True, env=env, timeout=900)
+                        "1", "--grid-res", "256", "--halo-check"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["triangles"] == 617180 and d["config"]["cells"] == 257 ** 3
     assert d["scaling"] == "strong" and d["value"] > 0
+    b = d["config"]["z_bounds"]                       # count-balanced slabs: still a partition of all 257 layers
+    assert b[0] == 0 and b[-1] == 257 and 0 < b[1] < 257
     # the halo plane a sampled-field design would exchange equals the plane each rank recomputes
     assert d["halo"]["recomputed_plane_identical_to_exchanged"] is True
 
