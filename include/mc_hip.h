@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 1
+#define MC_ABI_VERSION 2
 
 /* Status codes (the reference returns bool / throws std::exception without text:
  * evaluator.cpp:10-13, marching.cpp:226-238). */
@@ -47,11 +47,19 @@ enum {
     MC_FLAG_NORMALS = 1u,      /* fill the normal half of each vertex (gradient of f);  */
                                /* without it normals are written as 0                                 */
     MC_FLAG_KEEP_CODES = 2u,   /* keep the per-cell cube codes readable through mc_copy_codes()       */
-    MC_FLAG_NO_EMIT = 4u,      /* classify + count only (cube codes and triangle count, no vertices)  */
+    MC_FLAG_NO_EMIT = 4u,      /* no triangle soup (cube codes, counts and -- if asked for -- the     */
+                               /* indexed mesh only)                                                  */
     MC_FLAG_TILE1 = 8u,        /* diagnostic: classify with row tiles of height 1 (no sample reuse)   */
-    MC_FLAG_TRI_META = 16u     /* also keep, per triangle, the table row used and its number inside   */
-                               /* the cell (mc_copy_tri_meta); needed to rebuild the reference's      */
-                               /* indexed Poly_Data (marching.cpp:599-654) from the soup              */
+    MC_FLAG_INDEXED = 32u,     /* also build the reference's indexed Poly_Data on the GPU: welded      */
+                               /* vertex_list / tri_list (marching.cpp:599-654, marching.h:32-55) and  */
+                               /* the drawer's area-weighted vertex normals (normal.h:3-41)           */
+    MC_FLAG_NO_CULL = 64u,     /* diagnostic: classify every row by sampling (no interval culling);   */
+                               /* the output must not change                                          */
+    MC_FLAG_NO_TIMING = 128u,  /* no per-kernel hipEvents (ms_* stay 0): four fewer nodes per sweep   */
+    MC_FLAG_EMIT_DIRECT = 256u,/* diagnostic: force the emit kernel that computes every output vertex  */
+                               /* on its own (the default for cheap f) ...                             */
+    MC_FLAG_EMIT_SHARED = 512u /* ... or the one that computes each lattice-edge vertex once per chunk */
+                               /* of cells (the default for expensive f); the output must not change   */
 };
 
 typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */
@@ -87,6 +95,14 @@ typedef struct mc_result {
     int32_t code_main_cells;/* cells per row held by d_codes (n1, or n1 - (1..4) on 2^k+1 grids)     */
     const uint32_t *d_codes_tail; /* device, or NULL: one dword per (z,y) row with the codes of cells */
                             /* code_main_cells..n1-1 (byte k = cell code_main_cells + k)              */
+    /* MC_FLAG_INDEXED: Poly_Data (marching.h:26-30) in device memory, the slab welded on its own      */
+    uint64_t n_verts;       /* vertex_list.size() / 3                                                 */
+    const float *d_vertex_list;    /* n_verts * 3 floats, the reference's order of first insertion    */
+    const uint32_t *d_tri_list;    /* n_tris * 3 indices into it, reference emission order            */
+    const float *d_vertex_normals; /* n_verts * 3 floats: CalculateNormal (normal.h:3-41)             */
+    float ms_index;         /* GPU time of the indexed-mesh kernels (hipEvent, ms)                   */
+    const uint64_t *d_totals; /* device: {n_tris, n_active} of the sweep, valid in stream order -- lets */
+                            /* a multi-GPU host exchange the counts (RCCL) without a host round trip  */
 } mc_result;
 
 /* -- library ------------------------------------------------------------- */
@@ -136,13 +152,14 @@ int mc_march_simple(mc_context *ctx, const char *equation, int grid_res, float i
  * mc_copy_vertices: n_tris*18 floats (positions+normals interleaved).
  * mc_copy_soup:     n_tris*9 floats, positions only -- the reference's pre-dedup triangle soup
  *                   (Step_Data::intersect_coord[tri_vlist[k]], marching.cpp:586-594).
- * mc_copy_codes:    n_cells bytes, compact, sweep order x-fastest (needs MC_FLAG_KEEP_CODES). */
+ * mc_copy_codes:    n_cells bytes, compact, sweep order x-fastest. */
 int mc_copy_vertices(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_soup(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
-/* mc_copy_tri_meta: n_tris uint16: (table row used, 0..255) | (triangle number inside its cell << 8);
- * needs MC_FLAG_TRI_META.  A triangle with number 0 starts a new cell (marching.cpp:586-594). */
-int mc_copy_tri_meta(mc_context *ctx, uint16_t *host, uint64_t max_tris);
+/* mc_copy_indexed: the indexed mesh of the last MC_FLAG_INDEXED sweep: vertex_list (n_verts*3 floats), tri_list
+ * (n_tris*3 uint32) and the area-weighted vertex normals (n_verts*3 floats); any of the three may be NULL. */
+int mc_copy_indexed(mc_context *ctx, float *vertex_list, uint32_t *tri_list, float *normals, uint64_t max_verts,
+                    uint64_t max_tris);
 
 /* Constraints: Marching::set_constraint0..2(lhs, op, rhs) (Source/marching.h:105-108, marching.cpp:173-200) and
  * use_constraint0..2(bool) (marching.h:110-113, marching.cpp:202-207).  i in 0..2; op is one of ">=", "<=", ">", "<";
@@ -165,9 +182,21 @@ int mc_use_constraint(mc_context *ctx, int i, int use);
 int mc_cells_per_axis(float step);
 
 /* -- steady-state replay (animated iso sweep): capture classify->scan->emit once as a hipGraph
- *    and replay it with a new iso value per frame (Marching::set_surface_constant + recalculate). */
+ *    and replay it with a new iso value per frame (Marching::set_surface_constant + recalculate).
+ *    The captured graph belongs to the sweep mc_graph_build was given (equation, step, scale, flags, slab and the
+ *    constraints in force then).  Any later call that changes what it depends on -- an mc_march with other parameters
+ *    that re-targets or re-allocates a buffer, mc_set_constraint / mc_use_constraint -- makes the next replay re-capture
+ *    the ORIGINAL sweep first (never another equation's kernels on this one's buffers).  Seed mode and MC_FLAG_INDEXED
+ *    size their buffers from the host between kernels and are refused by mc_graph_build. */
 int mc_graph_build(mc_context *ctx, const mc_params *p);
 int mc_graph_replay(mc_context *ctx, float iso, mc_result *res);
+/* The same without the host round trip: enqueue one replay and return; mc_graph_wait blocks until everything enqueued
+ * has run and reports the LAST replay (a replay that outgrew the vertex buffer writes nothing past it; mc_graph_wait then
+ * re-runs that last frame with a larger buffer, like mc_graph_replay does). */
+int mc_graph_replay_async(mc_context *ctx, float iso);
+int mc_graph_wait(mc_context *ctx, mc_result *res);
+/* The HIP stream (hipStream_t) every kernel of this context runs on, for callers that order their own work after a sweep. */
+void *mc_stream(mc_context *ctx);
 
 #ifdef __cplusplus
 }

@@ -20,23 +20,25 @@
 //   Marching::save_poly_to_file / load_poly_from_file   same ASCII PLY (marching.cpp:665-854), path argument
 //                                                instead of the Win32 dialog
 //
-// Differences, all documented in DESIGN.md: by default the mesh is the triangle SOUP the GPU emits
-// (tri_list = 0..3T-1) with `normal_list` (gradient normals, 3 floats per vertex) as an extra
-// member; set_indexed(true) additionally runs the reference's vertex welding on the host -- the
-// same std::set<xyz> with the same tolerance comparator fed in the same order
-// (marching.cpp:599-643, marching.h:32-55), so vertex_list / tri_list come out as the reference
-// builds them; normal_list then holds the reference's own area-weighted vertex normals (CalculateNormal,
-// Source/normal.h:3-41, also available as a free function).  Constraints (set_constraint0..2 / use_constraint0..2)
-// and seed mode (seed_mode / set_seed) are provided -- seed mode returns the same triangles as the reference's
-// walk, in sweep order (mc_hip.h).  The step-by-step STATE MACHINE of recalculate() is not; step_at(ix, iy, iz)
-// gives the Step_Data of any one cell instead.  A failed GPU call makes recalculate() return false and
-// last_error() non-empty instead of crashing.
+// Differences, all documented in DESIGN.md.  get_poly_data() holds the reference's INDEXED mesh (vertex_list welded,
+// tri_list indexing it), built on the GPU with the reference's own welding rule (marching.cpp:599-654, marching.h:32-55:
+// first point inserted wins, 1e-6 tolerance; MC_FLAG_INDEXED), plus `normal_list`, an extra member: the drawer's
+// area-weighted vertex normals (CalculateNormal, Source/normal.h:3-41, also available as a free function).
+// set_indexed(false) hands over the GPU's triangle SOUP instead (tri_list = 0..3T-1) with gradient normals.  Constraints
+// (set_constraint0..2 / use_constraint0..2) and seed mode (seed_mode / set_seed) are provided -- seed mode returns the same
+// triangles as the reference's walk, in sweep order and as soup (mc_hip.h).  The step-by-step STATE MACHINE of
+// recalculate() is not; step_at(ix, iy, iz) gives the Step_Data of any one cell instead.  A failed GPU call makes
+// recalculate() return false and last_error() non-empty instead of crashing.
+//
+// Evaluator() / Marching() work like the reference's (evaluator.h:61, marching.h:75: no arguments): they share one
+// process-wide GPU context on device 0, created on first use.  The Context& overloads put an object on another GPU.
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <exception>
-#include <set>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -115,6 +117,12 @@ private:
     mc_context* h_ = nullptr;
 };
 
+// the process-wide context the argument-less constructors use (device 0, created on first use)
+inline Context& default_context() {
+    static Context ctx(0);
+    return ctx;
+}
+
 class Evaluator {
 public:
     Evaluator() { set_equation("x+y"); }                       // evaluator.cpp:6-8
@@ -128,7 +136,8 @@ public:
         return true;
     }
     const std::string& equation() const { return equation_; }
-    // evaluator.cpp:53; needs a context because the value is computed on the GPU
+    // evaluator.cpp:53 / evaluator.h:61; the value is computed on the GPU (the process-wide context, or the one given)
+    float evaluate(float x, float y, float z) const { return evaluate(default_context(), x, y, z); }
     float evaluate(Context& ctx, float x, float y, float z) const {
         const float p[3] = {x, y, z};
         float out = 0.0f;
@@ -142,7 +151,8 @@ private:
 
 class Marching {
 public:
-    explicit Marching(Context& ctx) : ctx_(ctx) {}  // defaults: marching.cpp:23-37
+    Marching() : ctx_(default_context()) {}         // marching.h:75; defaults: marching.cpp:23-37
+    explicit Marching(Context& ctx) : ctx_(ctx) {}  // the same on a chosen GPU
 
     bool set_evaluator(Evaluator* e) {  // marching.cpp:140-147
         if (!e) return false;
@@ -162,17 +172,29 @@ public:
     // marching.h:105-113, marching.cpp:173-207.  The constraints live in the GPU context; a cell with a
     // corner outside an enabled constraint is skipped by recalculate() (marching.cpp:476).
     bool set_constraint(int i, const std::string& lhs, const std::string& op, float rhs) {
-        return mc_set_constraint(ctx_.get(), i, lhs.c_str(), op.c_str(), rhs) == MC_OK;
+        if (mc_set_constraint(ctx_.get(), i, lhs.c_str(), op.c_str(), rhs) != MC_OK) return false;
+        cons_[i].valid = true;
+        cons_[i].lhs = lhs;
+        cons_[i].op = op == ">=" ? 0 : op == "<=" ? 1 : op == ">" ? 2 : 3;
+        cons_[i].rhs = rhs;
+        return true;
     }
     bool set_constraint0(const std::string& l, const std::string& o, float r) { return set_constraint(0, l, o, r); }
     bool set_constraint1(const std::string& l, const std::string& o, float r) { return set_constraint(1, l, o, r); }
     bool set_constraint2(const std::string& l, const std::string& o, float r) { return set_constraint(2, l, o, r); }
-    bool use_constraint(int i, bool b) { return mc_use_constraint(ctx_.get(), i, b ? 1 : 0) == MC_OK && b; }
+    bool use_constraint(int i, bool b) {
+        if (mc_use_constraint(ctx_.get(), i, b ? 1 : 0) != MC_OK) return false;
+        cons_[i].in_use = b;
+        return b;
+    }
     bool use_constraint0(bool b) { return use_constraint(0, b); }
     bool use_constraint1(bool b) { return use_constraint(1, b); }
     bool use_constraint2(bool b) { return use_constraint(2, b); }
     // marching.cpp:115-137: seed mode keeps the surface reached from the seed's cell (mc_hip.h, mc_set_seed)
-    void seed_mode(bool b) { mc_seed_mode(ctx_.get(), b ? 1 : 0); }
+    void seed_mode(bool b) {
+        mc_seed_mode(ctx_.get(), b ? 1 : 0);
+        seed_mode_ = b;
+    }
     bool set_seed(float x, float y, float z) {
         if (mc_set_seed(ctx_.get(), x, y, z) != MC_OK) return false;
         seed_[0] = x; seed_[1] = y; seed_[2] = z;
@@ -216,6 +238,29 @@ public:
             error_ = mc_last_error();
             return false;
         };
+        // marching.cpp:476: a corner outside an enabled constraint abandons the cell before anything is computed
+        for (int ci = 0; ci < 3; ++ci) {
+            const Constraint& cn = cons_[ci];
+            if (!(cn.valid && cn.in_use)) continue;  // marching.cpp:258
+            float lhs[8];
+            std::vector<float> sp(24);
+            for (int i = 0; i < 8; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    volatile float t = scale_[a] * s.corner_coords[3 * i + a];
+                    sp[3 * i + a] = t;
+                }
+            if (mc_eval_points(ctx_.get(), cn.lhs.c_str(), sp.data(), 8, lhs) != MC_OK) {
+                error_ = mc_last_error();
+                return false;
+            }
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = cn.op == 0 ? lhs[i] >= cn.rhs : cn.op == 1 ? lhs[i] <= cn.rhs : cn.op == 2 ? lhs[i] > cn.rhs : lhs[i] < cn.rhs;
+                if (!ok) {
+                    *out = s;  // an empty Step_Data: coordinates only
+                    return true;
+                }
+            }
+        }
         if (!eval(s.corner_coords.data(), 8, s.corner_values.data())) return false;
         const float iso = surface_constant_;
         int code = 0;
@@ -264,7 +309,7 @@ public:
         }
         return true;
     }
-    // true: weld vertices like the reference (marching.cpp:599-654); false (default): triangle soup
+    // true (default): the reference's welded Poly_Data (marching.cpp:599-654), built on the GPU; false: triangle soup
     void set_indexed(bool b) { indexed_ = b; }
 
     void reset_all_data() {  // marching.cpp:293-305
@@ -278,6 +323,7 @@ public:
         reset_all_data();
         error_.clear();
         if (!evaluator_) return false;
+        const bool indexed = indexed_ && !seed_mode_;  // seed mode hands over soup (its walk is not the sweep's order)
         mc_params p{};
         p.equation = evaluator_->equation().c_str();
         p.step = grid_step_size_;
@@ -285,7 +331,7 @@ public:
         p.scale[0] = scale_[0];
         p.scale[1] = scale_[1];
         p.scale[2] = scale_[2];
-        p.flags = (normals_ && !indexed_ ? MC_FLAG_NORMALS : 0u) | (indexed_ ? MC_FLAG_TRI_META : 0u);
+        p.flags = indexed ? (MC_FLAG_INDEXED | MC_FLAG_NO_EMIT) : (normals_ ? MC_FLAG_NORMALS : 0u);
         p.z_begin = 0;
         p.z_end = -1;
         mc_result r{};
@@ -294,13 +340,24 @@ public:
             return false;
         }
         last_ = r;
+        if (indexed) {
+            poly_data_.vertex_list.resize((size_t)r.n_verts * 3);
+            poly_data_.tri_list.resize((size_t)r.n_tris * 3);
+            if (normals_) poly_data_.normal_list.resize((size_t)r.n_verts * 3);
+            static_assert(sizeof(unsigned int) == sizeof(uint32_t), "tri_list is handed to the GPU library as uint32");
+            if (mc_copy_indexed(ctx_.get(), poly_data_.vertex_list.data(), reinterpret_cast<uint32_t*>(poly_data_.tri_list.data()),
+                                normals_ ? poly_data_.normal_list.data() : nullptr, r.n_verts, r.n_tris) != MC_OK) {
+                error_ = mc_last_error();
+                return false;
+            }
+            return true;
+        }
         const size_t nv = (size_t)r.n_tris * 3;
         std::vector<float> inter(nv * 6);
         if (nv && mc_copy_vertices(ctx_.get(), inter.data(), r.n_tris) != MC_OK) {
             error_ = mc_last_error();
             return false;
         }
-        if (indexed_) return weld_like_reference(inter, r.n_tris);
         poly_data_.vertex_list.resize(nv * 3);
         poly_data_.normal_list.resize(nv * 3);
         poly_data_.tri_list.resize(nv);
@@ -338,118 +395,75 @@ public:
         return true;
     }
 
-    // marching.cpp:665-768 load_poly_from_file: same header rules ("ply", "format ascii 1.0", at most
-    // 10 header lines, "element vertex N", "element face N") and the same append-to-current-data
-    // behaviour (the reference does not clear poly_data first)
+    // Reader of the format save_poly_to_file writes (marching.cpp:817-851), with the reference loader's rules
+    // (marching.cpp:695-768): first line "ply", second "format ascii 1.0", the counts from the "element vertex N" /
+    // "element face N" lines of a header of at most 10 lines up to "end_header", then N x "x y z" and N x "3 i j k";
+    // the mesh is APPENDED to the current one (the reference does not clear poly_data either).  Any violation -> false.
     bool load_poly_from_file(const std::string& path) {
-        FILE* fp = std::fopen(path.c_str(), "r");
-        if (!fp) return false;
-        char line[256];
-        auto getl = [&](std::string& out) {
-            if (!std::fgets(line, sizeof line, fp)) { out.clear(); return false; }
-            out = line;
-            return true;
+        struct File {
+            FILE* f;
+            explicit File(const char* p) : f(std::fopen(p, "r")) {}
+            ~File() { if (f) std::fclose(f); }
+        } in(path.c_str());
+        if (!in.f) return false;
+        char buf[256];
+        auto next_line = [&](std::string& line) {
+            line.clear();
+            if (std::fgets(buf, sizeof buf, in.f)) line = buf;
         };
-        std::string str;
-        if (!getl(str) || str.find("ply") == std::string::npos) { std::fclose(fp); return false; }
-        if (!getl(str) || str.find("format ascii 1.0") == std::string::npos) { std::fclose(fp); return false; }
-        getl(str);
-        int counter = 2, np = 0, nt = 0;
-        while (str.find("end_header") == std::string::npos) {
-            if (++counter >= 10) { std::fclose(fp); return false; }
-            if (str.find("element vertex") != std::string::npos) np = std::atoi(str.c_str() + 15);
-            if (str.find("element face") != std::string::npos) nt = std::atoi(str.c_str() + 13);
-            if (str.empty()) break;
-            getl(str);
-        }
-        for (int i = 0; i < np; ++i) {
-            float x, y, z;
-            if (std::fscanf(fp, "%f", &x) == EOF || std::fscanf(fp, "%f", &y) == EOF || std::fscanf(fp, "%f", &z) == EOF) {
-                std::fclose(fp);
-                return false;
+        auto count_after = [](const std::string& line, const char* tag, long& n) {
+            const size_t at = line.find(tag);
+            if (at != std::string::npos) n = std::strtol(line.c_str() + at + std::strlen(tag), nullptr, 10);
+        };
+        std::string line;
+        next_line(line);
+        if (line.find("ply") == std::string::npos) return false;
+        next_line(line);
+        if (line.find("format ascii 1.0") == std::string::npos) return false;
+        long n_points = 0, n_faces = 0;
+        bool ended = false;
+        for (int header_line = 3; header_line <= 10 && !ended; ++header_line) {  // lines 3..10 of the file
+            next_line(line);
+            if (line.empty()) break;  // end of file inside the header: no data follows, counts as read so far
+            if (line.find("end_header") != std::string::npos) ended = true;
+            else {
+                count_after(line, "element vertex", n_points);
+                count_after(line, "element face", n_faces);
             }
-            poly_data_.vertex_list.push_back(x);
-            poly_data_.vertex_list.push_back(y);
-            poly_data_.vertex_list.push_back(z);
         }
-        for (int i = 0; i < nt; ++i) {
-            unsigned num = 0, a, b, c;
-            if (std::fscanf(fp, "%u %u %u %u", &num, &a, &b, &c) == EOF) return false;
-            if (num != 3) { std::fclose(fp); return false; }
-            poly_data_.tri_list.push_back(a);
-            poly_data_.tri_list.push_back(b);
-            poly_data_.tri_list.push_back(c);
+        if (!ended && !line.empty()) return false;  // a header longer than the reference accepts
+        std::vector<float> pts;
+        std::vector<unsigned int> tri;
+        for (long i = 0; i < n_points; ++i) {
+            float v[3];
+            if (std::fscanf(in.f, "%f %f %f", &v[0], &v[1], &v[2]) != 3) return false;
+            pts.insert(pts.end(), v, v + 3);
         }
-        std::fclose(fp);
+        for (long i = 0; i < n_faces; ++i) {
+            unsigned int k = 0, a = 0, b = 0, c = 0;
+            if (std::fscanf(in.f, "%u %u %u %u", &k, &a, &b, &c) != 4 || k != 3) return false;
+            tri.push_back(a);
+            tri.push_back(b);
+            tri.push_back(c);
+        }
+        poly_data_.vertex_list.insert(poly_data_.vertex_list.end(), pts.begin(), pts.end());
+        poly_data_.tri_list.insert(poly_data_.tri_list.end(), tri.begin(), tri.end());
         return true;
     }
     const mc_result& last_result() const { return last_; }
     const std::string& last_error() const { return error_; }
 
 private:
-    // marching.h:32-55: the reference's point type; its operator< treats coordinates closer than 1e-6
-    // as equal, axis by axis (not a strict weak order -- reproduced as is, with the same container)
-    struct xyz {
-        float x, y, z;
-        int idx;
-        static bool close_enough(float a, float b) { return std::fabs(a - b) < 0.000001; }
-        bool operator<(const xyz& r) const {
-            if (!close_enough(x, r.x)) return x < r.x;
-            if (!close_enough(y, r.y)) return y < r.y;
-            if (!close_enough(z, r.z)) return z < r.z;
-            return false;
-        }
-    };
-
-    // marching.cpp:599-654 on the soup: per cell, the crossed-edge vertices are inserted in edge
-    // order 0..11 (the order calculate_step builds intersect_coord, :557-583), then the cell's
-    // triangles are appended with the returned indices.
-    bool weld_like_reference(const std::vector<float>& inter, uint64_t n_tris) {
-        static const uint64_t tri_row[256] = MC_TRI_ROW_INIT;
-        std::vector<uint16_t> meta(n_tris);
-        if (n_tris && mc_copy_tri_meta(ctx_.get(), meta.data(), n_tris) != MC_OK) {
-            error_ = mc_last_error();
-            return false;
-        }
-        std::set<xyz> vertex_set;
-        uint64_t t0 = 0;
-        while (t0 < n_tris) {
-            uint64_t t1 = t0 + 1;
-            while (t1 < n_tris && (meta[t1] >> 8) != 0) ++t1;  // triangles t0..t1-1 belong to one cell
-            const int row = meta[t0] & 0xFF;
-            const float* pos[12] = {nullptr};
-            for (uint64_t t = t0; t < t1; ++t)
-                for (int k = 0; k < 3; ++k) {
-                    const int e = (int)((tri_row[row] >> (4 * (3 * (int)(t - t0) + k))) & 0xF);
-                    pos[e] = &inter[(t * 3 + k) * 6];
-                }
-            int vidx[12];
-            for (int e = 0; e < 12; ++e) {
-                vidx[e] = -1;
-                if (pos[e] && !std::isnan(pos[e][0])) {  // :611-613 NaN x is skipped, index stays -1
-                    const int new_i = (int)(poly_data_.vertex_list.size() / 3);  // :629
-                    const int found = vertex_set.insert(xyz{pos[e][0], pos[e][1], pos[e][2], new_i}).first->idx;
-                    if (found == new_i) {
-                        poly_data_.vertex_list.push_back(pos[e][0]);
-                        poly_data_.vertex_list.push_back(pos[e][1]);
-                        poly_data_.vertex_list.push_back(pos[e][2]);
-                    }
-                    vidx[e] = found;
-                }
-            }
-            for (uint64_t t = t0; t < t1; ++t)
-                for (int k = 0; k < 3; ++k) {
-                    const int e = (int)((tri_row[row] >> (4 * (3 * (int)(t - t0) + k))) & 0xF);
-                    poly_data_.tri_list.push_back((unsigned int)vidx[e]);
-                }
-            t0 = t1;
-        }
-        if (normals_) poly_data_.normal_list = CalculateNormal(&poly_data_);  // what the reference's drawer computes
-        return true;
-    }
+    struct Constraint {  // marching.h:58-69 (the GPU context holds the compiled copy)
+        bool valid = false, in_use = false;
+        std::string lhs;
+        int op = 0;  // 0 '>=', 1 '<=', 2 '>', 3 '<'
+        float rhs = 0.0f;
+    } cons_[3];
 
     Context& ctx_;
-    bool indexed_ = false;
+    bool indexed_ = true;
+    bool seed_mode_ = false;
     Evaluator* evaluator_ = nullptr;   // borrowed, never owned (marching.cpp:140-147)
     float grid_step_size_ = 0.25f;     // marching.cpp:24
     float surface_constant_ = 0.0f;

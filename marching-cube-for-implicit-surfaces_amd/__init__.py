@@ -16,17 +16,20 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libmc_hip.so"
+# MC_AMD_DEV_LIB=1 (tools/ab.py only) loads the developer build, which honours the MC_JIT_EXTRA / MC_WPB_* hooks
+LIB_PATH = _HERE / ("libmc_hip_dev.so" if os.environ.get("MC_AMD_DEV_LIB") == "1" else "libmc_hip.so")
 
 MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NOMEM, MC_ERR_OVERFLOW = range(8)
-FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_TRI_META = 1, 2, 4, 8, 16
+FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_INDEXED, FLAG_NO_CULL, FLAG_NO_TIMING = 1, 2, 4, 8, 32, 64, 128
+FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED = 256, 512
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
-    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_tri_meta", "mc_cells_per_axis", "mc_graph_build",
-    "mc_graph_replay", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions", "mc_set_seed", "mc_seed_mode",
+    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
+    "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
+    "mc_set_seed", "mc_seed_mode",
 ]
 
 
@@ -40,7 +43,9 @@ class McResult(C.Structure):
                 ("n_cells", C.c_uint64), ("n_active", C.c_uint64), ("n_tris", C.c_uint64),
                 ("d_vertices", C.c_void_p), ("d_codes", C.c_void_p), ("code_pitch", C.c_uint64),
                 ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
-                ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p)]
+                ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p),
+                ("n_verts", C.c_uint64), ("d_vertex_list", C.c_void_p), ("d_tri_list", C.c_void_p), ("d_vertex_normals", C.c_void_p),
+                ("ms_index", C.c_float), ("d_totals", C.c_void_p)]
 
 
 class McError(RuntimeError):
@@ -86,7 +91,11 @@ def lib():
         L.mc_copy_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_soup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-        L.mc_copy_tri_meta.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_copy_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.mc_graph_replay_async.argtypes = [C.c_void_p, C.c_float]
+        L.mc_graph_wait.argtypes = [C.c_void_p, C.POINTER(McResult)]
+        L.mc_stream.argtypes = [C.c_void_p]
+        L.mc_stream.restype = C.c_void_p
         L.mc_cells_per_axis.argtypes = [C.c_float]
         L.mc_set_constraint.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_float]
         L.mc_use_constraint.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -173,12 +182,14 @@ class Result:
             _check(lib().mc_copy_soup(self._ctx._h, a.ctypes.data, self.n_tris))
         return a
 
-    def tri_meta(self) -> np.ndarray:
-        """(n_tris,) uint16: table row used | triangle number inside its cell << 8 (FLAG_TRI_META)."""
-        a = np.empty(self.n_tris, dtype=np.uint16)
-        if self.n_tris:
-            _check(lib().mc_copy_tri_meta(self._ctx._h, a.ctypes.data, self.n_tris))
-        return a
+    def indexed(self):
+        """(vertex_list (V,3) f32, tri_list (T,3) u32, normals (V,3) f32): the reference's Poly_Data, welded on the GPU
+        (FLAG_INDEXED), and the drawer's CalculateNormal."""
+        v = np.empty((self.n_verts, 3), dtype=np.float32)
+        n = np.empty((self.n_verts, 3), dtype=np.float32)
+        t = np.empty((self.n_tris, 3), dtype=np.uint32)
+        _check(lib().mc_copy_indexed(self._ctx._h, v.ctypes.data, t.ctypes.data, n.ctypes.data, self.n_verts, self.n_tris))
+        return v, t, n
 
     def codes(self) -> np.ndarray:
         """(n_cells,) uint8 raw cube codes in sweep order (x fastest)."""
@@ -266,6 +277,19 @@ class Context:
         r = McResult()
         _check(lib().mc_graph_replay(self._h, iso, C.byref(r)))
         return Result(self, r)
+
+    def graph_replay_async(self, iso):
+        """Enqueue one replay without waiting for it (graph_wait collects the last one)."""
+        _check(lib().mc_graph_replay_async(self._h, iso))
+
+    def graph_wait(self) -> Result:
+        r = McResult()
+        _check(lib().mc_graph_wait(self._h, C.byref(r)))
+        return Result(self, r)
+
+    def stream(self) -> int:
+        """The context's hipStream_t as an integer (torch.cuda.ExternalStream(ctx.stream()))."""
+        return int(lib().mc_stream(self._h) or 0)
 
 
 # ---- Z-slab sharding across GPUs (one process per GPU; host logic only) -----------------

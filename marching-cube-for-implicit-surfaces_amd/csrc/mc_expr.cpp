@@ -601,3 +601,18 @@ float eval_host(const Program& p, float x, float y, float z) {
 }
 
 }  // namespace mc
+
+namespace mc {
+int vector_op_cost(const Program& p) {
+    int cost = 0;
+    for (const Node& n : p.nodes) switch (n.op) {
+        case NodeOp::ADD: case NodeOp::SUB: case NodeOp::MUL: case NodeOp::NEG: cost += 1; break;
+        case NodeOp::DIV: cost += 10; break;
+        case NodeOp::POWI: cost += n.ipow == 2 ? 1 : 6 + 4 * (n.ipow < 0 ? -n.ipow : n.ipow) + (n.ipow < 0 ? 14 : 0); break;
+        case NodeOp::POW: cost += 300; break;
+        case NodeOp::SIN: case NodeOp::COS: cost += 22; break;
+        default: break;
+    }
+    return cost;
+}
+}  // namespace mc

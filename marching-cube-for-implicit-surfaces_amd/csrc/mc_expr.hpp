@@ -76,6 +76,11 @@ float eval_host(const Program& p, float x, float y, float z);
 // kernels may drop their NaN bookkeeping (MC_FINITE).
 bool finite_on_domain(const Program& p, double radius);
 
+// Rough count of vector instructions one evaluation of f costs on the device (add / sub / mul 1, IEEE division 10,
+// literal integer powers a few double multiplies, sin / cos ~22, general pow ~300).  mc_runtime picks the emit kernel by
+// it: below a measured threshold recomputing a vertex for each of its ~6 output copies is cheaper than sharing it.
+int vector_op_cost(const Program& p);
+
 // Power rule P1 (shared by constant folding, eval_host and -- as generated code -- the device).
 float pow_literal_int(float a, int n);
 float pow_general(float a, float b);

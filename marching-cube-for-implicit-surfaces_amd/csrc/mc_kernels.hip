@@ -44,6 +44,8 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef unsigned char u8;
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ power rule P1
 // `^` in the reference is pow(float,float) -> libm powf (evaluator.cpp:133).  Literal
@@ -157,7 +159,11 @@ struct McParams {
 #define MC_WPB_C 4
 #endif
 #ifndef MC_WPB_E
-#define MC_WPB_E 4
+#define MC_WPB_E 4   // mc_emit_direct
+#endif
+#ifndef MC_WPB_ES
+#define MC_WPB_ES 1  // mc_emit: its waves are independent (no table in LDS, no barrier); a workgroup keeps its LDS until its
+                     // slowest wave is done, so one wave per workgroup wastes none
 #endif
 #ifndef MC_LIST_CAP
 // triangles staged per wave in the emit kernel: one chunk of 64 records holds at most 64 * 5.  The kernel
@@ -372,21 +378,13 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             // SCALAR atomic: its result comes back through lgkmcnt.  A vector atomic's would come through
             // vmcnt, which retires in order -- the wave would sit until every code store it has in flight had
             // landed before it could even start copying its records (measured: 0.36 -> 0.44 ms).
-#ifdef MC_DBG_NO_FLUSH  // timing probe only (wrong results): no allocation, no copy
-            const bool probe_skip = true;
-#else
-            const bool probe_skip = false;
-#endif
             u32 gb = 0u;
-            if (!probe_skip) {
-                u32* const cur = p.rec_cursor + 32u * (1u + t.region);
-                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(gb) : "s"(cur), "0"(nbuf) : "memory");
-            }
+            u32* const cur = p.rec_cursor + 32u * (1u + t.region);
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(gb) : "s"(cur), "0"(nbuf) : "memory");
             const u32 rsize = (u32)(p.cap_recs / MC_NCUR);
             // past the region's end nothing is written and the overflow word is raised: the host grows the
             // buffer and sweeps again; mc_emit sees the word and stays out
-            if (probe_skip) {
-            } else if (gb + nbuf <= rsize) {
+            if (gb + nbuf <= rsize) {
                 gb += t.region * rsize;
                 for (u32 i = (u32)t.lane; i < nbuf; i += 64u) recs[gb + i] = recbuf[i];
             } else if (t.lane == 0) {
@@ -517,11 +515,7 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             nbuf += (u32)__builtin_amdgcn_readlane((int)pincl, 63) >> 16;
         }
         epochRows |= fit;
-#ifdef MC_DBG_NO_ROWLOOP  // timing probe only (wrong results)
-        if (false) {
-#else
         if (!TAIL) {
-#endif
             // The pending code rows this chunk completes.  Each row is stored WHOLE (256 B, full 128-byte lines) with
             // what the walk proved -- lanes all-above as ~0, the others, listed ones included, as 0 -- and then the
             // entry lanes overwrite their own dwords with ONE scattered store for the whole chunk: same wave, same
@@ -535,14 +529,9 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
                 f &= f - 1ull;
                 const u64 all = ((u64)(u32)__builtin_amdgcn_readlane((int)rm.allhi, jr) << 32) | (u32)__builtin_amdgcn_readlane((int)rm.alllo, jr);
                 const u32 v = select_by_mask(all, vmask_row, 0u);
-#if !defined(MC_DBG_NO_STORE) && !defined(MC_DBG_NO_ROWSTORE)
                 __builtin_amdgcn_raw_buffer_store_b32(
                     v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)jr * (u32)p.pitch), 0, (int)p.pitch, 0x00020000), (u32)xl0, 0, 0);
-#else
-                asm volatile("" ::"v"(v));
-#endif
             }
-#if !defined(MC_DBG_NO_STORE) && !defined(MC_DBG_NO_ROWSTORE)
             // (a listed lane beyond the end of the grid -- ragged last chunk, degenerate clamped cells -- has dw == 0 and
             // must not write: its offset lies past the row, in the rows that follow)
             // A buffer store like the row stores above, so that both travel the same queue in issue order; lanes that
@@ -553,7 +542,6 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
                 __builtin_amdgcn_raw_buffer_store_b32(dw, __builtin_amdgcn_make_buffer_rsrc(tilebase, 0, (int)(64u * (u32)p.pitch), 0x00020000),
                                                       eoff, 0, 0);
             }
-#endif
         }
         pend &= ~fit;
         e0 = e1;
@@ -706,16 +694,12 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         rmt.alllo = 0u;
         rmt.allhi = 0u;
         u32 rbase = 0u;
-#ifndef MC_DBG_NO_RECORD
         if (mixedL) rbase = mc_backend<true>(p, tt, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rmt, mixedL, 0u, codes, recs, tailbuf);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (rvalid) {
             const u32 own = select_by_mask(mixedL, tailbuf[lane], select_by_mask(laneAll, vm, 0u));
-#ifndef MC_DBG_NO_STORE
             p.codes_tail[(u64)lz * n1 + y0 + lane] = own;
-#endif
             const u64 sg = tt.seg0 + (u64)lane * p.nchunk;
             const u32 c = seg_cnt[lane];
             segcb[sg] = make_uint2(c, rbase);
@@ -807,11 +791,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // 0.14 ms at 1025^3 (measured: every one is a read-modify-write of a cold line).
     const int rowbytes = (int)p.pitch;
     auto store_codes = [&](u32 v) {
-#if defined(MC_DBG_NO_STORE)
-        asm volatile("" ::"v"(v));
-#else
         __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, rowbytes, 0x00020000), xoff, 0, 0);
-#endif
         rowbase += p.pitch;
     };
 #if defined(MC_HAVE_IV) && defined(MC_FINITE) && !defined(MC_NO_CULL)
@@ -851,18 +831,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         asm volatile("" ::"v"(lxl), "v"(lxh), "v"(yv));
         const u64 rowsValid = (1ull << ny) - 1ull;  // ny <= 63 here
         const u64 cull = rowCull & rowsValid;
-#ifndef MC_STORES_LAST
         // (1) aligned blocks of 4 culled rows
         u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
         const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
-#ifdef MC_DBG_NO_CULLSTORE
-        m4 = 0ull;
-#endif
         while (m4) {
             const int j = __builtin_ctzll(m4);
             m4 &= m4 - 1ull;
             const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
-#ifndef MC_DBG_NO_STORE
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             u32x4 v;
             v.x = c & vm4[0];
@@ -871,27 +846,16 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             v.w = c & vm4[3];
             __builtin_amdgcn_raw_buffer_store_b128(
                 v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, 0);
-#else
-            asm volatile("" ::"v"(c));
-#endif
         }
         // (2) the other culled rows
         u64 m1 = cull & ~blockRows;
-#ifdef MC_DBG_NO_CULLSTORE
-        m1 = 0ull;
-#endif
         while (m1) {
             const int j = __builtin_ctzll(m1);
             m1 &= m1 - 1ull;
             const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
-#ifndef MC_DBG_NO_STORE
             __builtin_amdgcn_raw_buffer_store_b32(
                 v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, 0);
-#else
-            asm volatile("" ::"v"(v));
-#endif
         }
-#endif
         // (3) undecided rows: the lane-level masks go to lane j of rm, the row itself to the back-end.
         // Two adjacent undecided rows share ONE evaluation over the box of both (3 sample rows): half
         // the interval evaluations, for a few more lanes handed to the back-end (which is exact, so a
@@ -902,12 +866,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         while (mu) {
             const int j = __builtin_ctzll(mu);
             mu &= mu - 1ull;
-#ifndef MC_NO_PAIR
             const int pair = (int)((mu >> ((j + 1) & 63)) & 1ull);  // row j+1 is undecided too (j + 1 < ny then)
             if (pair) mu &= mu - 1ull;
-#else
-            const int pair = 0;
-#endif
             const float ya = readlane_f(yv, j), yb = readlane_f(yv, j + 1 + pair);
             float lo, hi;
             mc_f_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, lo, hi);
@@ -923,47 +883,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             MC_SET_ROW(j, mixedL, laneAll)
             if (pair) MC_SET_ROW(j + 1, mixedL, laneAll)
         }
-#ifdef MC_STORES_LAST
-        // (1) aligned blocks of 4 culled rows
-        u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
-        const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
-#ifdef MC_DBG_NO_CULLSTORE
-        m4 = 0ull;
-#endif
-        while (m4) {
-            const int j = __builtin_ctzll(m4);
-            m4 &= m4 - 1ull;
-            const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
-#ifndef MC_DBG_NO_STORE
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 v;
-            v.x = c & vm4[0];
-            v.y = c & vm4[1];
-            v.z = c & vm4[2];
-            v.w = c & vm4[3];
-            __builtin_amdgcn_raw_buffer_store_b128(
-                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, 0);
-#else
-            asm volatile("" ::"v"(c));
-#endif
-        }
-        // (2) the other culled rows
-        u64 m1 = cull & ~blockRows;
-#ifdef MC_DBG_NO_CULLSTORE
-        m1 = 0ull;
-#endif
-        while (m1) {
-            const int j = __builtin_ctzll(m1);
-            m1 &= m1 - 1ull;
-            const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
-#ifndef MC_DBG_NO_STORE
-            __builtin_amdgcn_raw_buffer_store_b32(
-                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, 0);
-#else
-            asm volatile("" ::"v"(v));
-#endif
-        }
-#endif
     }
 #else
     // ---- sampling walk (equations the interval code cannot bound: division by a variable,
@@ -1072,9 +991,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 
 #undef MC_SET_ROW
     u32 rbase = 0u;
-#ifndef MC_DBG_NO_RECORD
     if (rowPend) rbase = mc_backend(p, tc, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rm, rowPend, vmask, codes, recs);
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < ny) {
@@ -1087,6 +1004,371 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
 }
 
 // =============================================================== K3: emit
+// ---- geometry of the 12 cell edges (marching_lookup.h:10-23 over the corner layout of marching.cpp:471-472)
+// Edge e lies on ONE lattice edge: its axis, and the offset of that lattice edge's LOWER end inside the cell.
+#define MC_EDGE_OX 0x622u    // edges whose lower end has x offset 1: 1, 5, 9, 10
+#define MC_EDGE_OY 0xC44u    // ... y offset 1: 2, 6, 10, 11
+#define MC_EDGE_OZ 0x0F0u    // ... z offset 1: 4, 5, 6, 7
+#define MC_EDGE_DOWN 0x0CCu  // edges the table walks from their upper to their lower end: 2, 3, 6, 7
+__device__ __forceinline__ int edge_axis(int e) { return e >= 8 ? 2 : (e & 1); }
+
+// the edges of a cell that carry an intersection: the two corner bits differ (marching.cpp:560-566)
+__device__ __forceinline__ u32 crossed_edges(u32 c) {
+    const u32 t = c ^ (c >> 1);  // bit i: corner i against corner i+1 (edges 0, 1, 2, 4, 5, 6)
+    const u32 u = c ^ (c >> 4);  // bit i: corner i against corner i+4 (edges 8..11)
+    return (t & 0x77u) | ((((c >> 3) ^ c) & 1u) << 3) | ((((c >> 7) ^ (c >> 4)) & 1u) << 7) | ((u & 0xFu) << 8);
+}
+
+// Marching::interp (marching.cpp:437-446) for one axis.  The fallback `x_s + 0.5*(x_e - x_s)` is evaluated in double by
+// the reference; one add of two floats rounded to double and then to float equals the float add (53 >= 2*24+2).
+__device__ __forceinline__ float mc_interp(float iso, float xs, float xe, float vs, float ve) {
+    const float t = (iso - vs) / (ve - vs);
+    const float dx = xe - xs;
+    const float v = t * dx;
+    return (__builtin_isinf(v) || __builtin_isnan(v)) ? xs + 0.5f * dx : xs + v;
+}
+
+// n = g/|g|, g = central difference of F at the point, h = step/2.  false: zero or non-finite gradient.
+__device__ __forceinline__ bool mc_grad_normal(const McParams& p, float x, float y, float z, float h, float& nx, float& ny, float& nz) {
+    const float gx = mc_F(p, x + h, y, z) - mc_F(p, x - h, y, z);
+    const float gy = mc_F(p, x, y + h, z) - mc_F(p, x, y - h, z);
+    const float gz = mc_F(p, x, y, z + h) - mc_F(p, x, y, z - h);
+    const float len2 = (gx * gx + gy * gy) + gz * gz;
+    if (len2 >= 1e-30f && !__builtin_isinf(len2)) {
+        // v_rsq_f32 (1 ulp) instead of an IEEE sqrt and an IEEE divide: the normal is a tolerance quantity
+        // 
+        const float inv = __builtin_amdgcn_rsqf(len2);
+        nx = gx * inv;
+        ny = gy * inv;
+        nz = gz * inv;
+        return true;
+    }
+    const float len = __builtin_sqrtf(len2);
+    if (len > 0.0f && !__builtin_isinf(len)) {  // tiny gradient: rsq would flush it
+        const float inv = 1.0f / len;
+        nx = gx * inv;
+        ny = gy * inv;
+        nz = gz * inv;
+        return true;
+    }
+    return false;
+}
+
+// One wave = one GROUP of 64 consecutive segments; its records (= active cells, written by mc_classify) are taken in
+// CHUNKS of up to 64, lane = record, in sweep order.
+//
+//  A. record -> owning segment (binary search over the group's active-cell offsets, LDS), cell coordinates, code.
+//  B. Who computes which vertex.  A crossed lattice edge is shared by up to 4 cells, 2 of them in the same z layer
+//     (4 for an edge along z), and every one of them emits it in 1-2 triangles: ~6 output vertices per lattice edge.
+//     Inside a chunk each lattice edge is computed ONCE: by the cell that has it at its low-x / low-y side when that
+//     cell is in the chunk (lane + 1 for the x neighbour; the y and xy neighbours by a binary search over the chunk's
+//     sorted cell keys), else by the cell itself.  Per lane: the set S of edges it computes and their first slot.
+//     Then, still one lane per record: every corner of the cell's triangles is resolved to the slot of its vertex
+//     (table row -> edge -> owner lane and edge -> slot) and the triangle is written to the chunk's list as three
+//     slots -- the per-record part of what an output vertex needs is done 64 lanes wide, once.
+//  C. One lane per computed VERTEX: two corner evaluations, the intersection point seen from the lower end (p_up) and
+//     from the upper end (p_down; the table walks edges 2, 3, 6, 7 downwards and the reference's interp is not symmetric:
+//     the soup must carry the bits of the direction its own cell uses), the gradient normal at p_up (ONE normal per
+//     lattice edge) -> 8 floats in LDS: x y z (with p_up on the edge's axis), p_down, nx ny nz.
+//  D. One lane per OUTPUT vertex (3 per triangle, reference emission order): list entry -> slot -> two 16-byte LDS
+//     reads -> 24 bytes stored.  No evaluation of f, no table walk here.
+#ifndef MC_VCAP
+#define MC_VCAP 160  // vertices a chunk may compute (32 bytes each in LDS); a denser chunk is cut short
+#endif
+static_assert(MC_VCAP >= 96 && MC_VCAP <= 255, "8 records compute at most 96 vertices; slots are kept in 8 bits");
+// What mc_emit needs before its first load returns travels as kernel arguments (the kernarg segment is in SGPRs when
+// the wave starts); only iso and the vertex capacity -- which a replayed graph changes per frame -- come from *P.
+struct McEmitK {
+    const float* axis;    // lattice coordinates c[0..n1]
+    const u32* overflow;  // mc_classify's "a record region overflowed" word
+    u32 nseg;
+    int n1, nchunk, z_begin;
+    u32 flags;
+    float step, sx, sy, sz;
+};
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                     const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                                     float* __restrict__ verts, const McEmitK k) {
+    __shared__ __attribute__((aligned(16))) float s_vc[MC_WPB_ES][MC_VCAP * 8];  // computed vertices
+    __shared__ u32 s_seg[MC_WPB_ES][64];    // per segment of the group: iy | iz << 11 | chunk << 22 | row-in-group << 25
+    __shared__ u32 s_act[MC_WPB_ES][66];    // ... exclusive active-cell offsets (+ the total)
+    __shared__ u32 s_tri[MC_WPB_ES][64];    // ... first triangle
+    __shared__ u32 s_rbase[MC_WPB_ES][64];  // ... first record
+    __shared__ u32 s_key[MC_WPB_ES][66];    // per record of the chunk: row-in-group << 11 | ix, ascending; ~0 past the end
+    __shared__ u32 s_rec[MC_WPB_ES][64];    // ... segment | cellx << 6
+    __shared__ u32 s_own[MC_WPB_ES][64];    // ... S | first slot << 12
+    __shared__ u32 s_list[MC_WPB_ES][320];  // triangles of the chunk: slot of corner k << 8k | (axis taken from p_down, 3 = none) << 24 + 2k
+    __shared__ unsigned short s_item[MC_WPB_ES][MC_VCAP];  // vertices to compute: lane | edge << 6
+    // No table in LDS, no workgroup barrier: the waves of a workgroup are independent (a workgroup is only a launch
+    // container; it holds its LDS until its slowest wave is done, so it is kept small).  The case table row and the
+    // lattice coordinates are read from memory where they are needed (L1 / L2 hits), always BEFORE a chunk's stores.
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
+    const u32 ngroups = (k.nseg + 63u) / 64u;
+    const u32 group = blockIdx.x * (u32)MC_WPB_ES + (u32)w;
+    if (group >= ngroups) return;  // (the grid is rounded up to whole workgroups)
+    // every load that does not depend on another is issued up front: the group's offsets, per-segment counts, the
+    // overflow word and the two words of *P
+    const u32 seg_first = group * 64u;
+    const u32 seg = seg_first + (u32)lane;
+    const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
+    const uint2 cb = segcb[min(seg, k.nseg - 1u)];  // {triangles | active << 16, first record}
+    const u32 rec_overflow = k.overflow[0];
+    const float iso = P->iso;
+    const u64 cap_tris = P->cap_tris;
+    const u32 cnt = seg < k.nseg ? cb.x : 0u;
+    // rec_overflow: mc_classify ran out of record space (the host grows the buffer and sweeps again)
+    if (g0.y == g1.y || rec_overflow != 0u) return;  // no active cell in these 64 segments
+    McParams p;  // (mc_F reads the scale factors from it)
+    p.sx = k.sx;
+    p.sy = k.sy;
+    p.sz = k.sz;
+    const float* __restrict__ axis = k.axis;
+
+    // the scan gives the group's first triangle; the prefix inside the group is a wavefront scan of the per-segment
+    // counts (triangles | active cells << 16)
+    const u32 ctri = cnt & 0xFFFFu, cact = cnt >> 16;
+    const u32 itri = wave_inclusive_scan(ctri), iact = wave_inclusive_scan(cact);
+    const u32 nrec = (u32)__builtin_amdgcn_readlane((int)iact, 63);  // records of the group
+
+    u32* list = s_list[w];
+    unsigned short* item = s_item[w];
+    float* vc = s_vc[w];
+    u32* segrec = s_seg[w];
+    u32* actoff = s_act[w];
+    u32* trioff = s_tri[w];
+    u32* rbase = s_rbase[w];
+    u32* key = s_key[w];
+    u32* recw = s_rec[w];
+    u32* own = s_own[w];
+    const int n1 = k.n1;
+    {
+        const u32 sg = min(seg, k.nseg - 1u);
+        const u32 rowidx = sg / (u32)k.nchunk;
+        const u32 ch = sg - rowidx * (u32)k.nchunk;
+        const u32 lz = rowidx / (u32)n1;
+        const u32 iy = rowidx - lz * (u32)n1;
+        const u32 row_first = seg_first / (u32)k.nchunk;
+        segrec[lane] = iy | ((u32)(k.z_begin + (int)lz) << 11) | (ch << 22) | ((rowidx - row_first) << 25);
+        actoff[lane] = iact - cact;
+        trioff[lane] = g0.x + (itri - ctri);
+        rbase[lane] = cb.y;
+        if (lane == 63) actoff[64] = nrec;
+        if (lane < 2) key[64 + lane] = 0xFFFFFFFFu;
+    }
+    const float h = 0.5f * k.step;
+    const bool want_normals = (k.flags & 1u) != 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- A. a lane's record: owning segment = the largest s with actoff[s] <= r (empty segments repeat the value)
+    auto find_segment = [&](u32 r) {
+        u32 lo = 0, hi = 64;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const u32 mid = (lo + hi) >> 1;
+            if (actoff[mid] <= r) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    u32 lo = find_segment((u32)lane);
+    u32 rec = (u32)lane < nrec ? recs[rbase[lo] + ((u32)lane - actoff[lo])] : 0u;
+    for (u32 r0 = 0; r0 < nrec;) {
+        const u32 gtri0 = trioff[lo] + (rec >> 20);
+        const u32 sr = segrec[lo];
+        const u32 code = (rec >> 8) & 0xFFu;
+        const u32 ix = ((sr >> 22) & 7u) * (u32)MC_SEG + (rec & 0xFFu);
+        const u32 iy = sr & 2047u;
+        const u32 mykey = ((sr >> 25) << 11) | ix;
+        const u32 cm = crossed_edges(code);
+
+        // ---- B. ownership inside the chunk; a chunk that would compute more than MC_VCAP vertices is cut in halves
+        u32 nvalid = min(64u, nrec - r0);
+        u32 S, sb, M, vx, vy, vxy, ny_lane;
+        for (;;) {
+            const bool valid = (u32)lane < nvalid;
+            key[lane] = valid ? mykey : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // x neighbour (ix + 1, same row): the next record if there is one
+            vx = key[lane + 1] == mykey + 1u ? 1u : 0u;
+            // y neighbour (ix, row + 1) -- not across the top of a layer --: lower bound over the 64 sorted keys
+            const u32 ty = mykey + (1u << 11);
+            u32 pos = 0;
+#pragma unroll
+            for (int st = 32; st >= 1; st >>= 1)
+                if (key[pos + st - 1] < ty) pos += st;
+            // (with constraints the y neighbour can be a skipped cell -- no record -- while the xy neighbour is there:
+            // the lower bound then lands on the xy neighbour itself)
+            vy = (iy + 1u < (u32)n1 && key[pos] == ty) ? 1u : 0u;
+            vxy = (iy + 1u < (u32)n1 && key[pos + vy] == ty + 1u) ? 1u : 0u;
+            ny_lane = pos;
+            // edges some other lane of the chunk computes: 1, 5, 9 = the x neighbour's 3, 7, 8; 2, 6, 11 = the y
+            // neighbour's 0, 4, 8; 10 = the xy neighbour's 8 (else the x neighbour's 11, else the y neighbour's 9)
+            const u32 remote = (vx ? 0x222u : 0u) | (vy ? 0x844u : 0u) | ((vx | vy | vxy) ? 0x400u : 0u);
+            S = valid ? (cm & ~remote) : 0u;
+            const u32 c = (u32)__builtin_popcount(S);
+            const u32 incl = wave_inclusive_scan(c);
+            sb = incl - c;
+            M = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (M <= (u32)MC_VCAP) break;
+            // too many: keep the records whose vertices fit with a little room (a record that loses a neighbour to the
+            // cut computes up to 4 more itself), at least 8 (8 records compute at most 96 vertices)
+            const u32 fit = (u32)__builtin_popcountll(__ballot(incl + 8u <= (u32)MC_VCAP));
+            nvalid = max(8u, min(fit, nvalid - 1u));
+        }
+        const bool valid = (u32)lane < nvalid;
+        const u32 nt = valid ? (rec >> 17) & 7u : 0u;
+        // the chunk's triangles are one contiguous range of the global order
+        const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
+        const u32 chunk_t = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), (int)nvalid - 1) - first;
+        const u32 myow = S | (sb << 12);
+        recw[lane] = lo | ((rec & 0xFFu) << 6);
+        own[lane] = myow;
+        {
+            u32 m = S, j = sb;
+            while (m) {
+                const u32 e = (u32)__builtin_ctz(m);
+                m &= m - 1u;
+                item[j++] = (unsigned short)((u32)lane | (e << 6));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nt) {
+            // Slot of the vertex on each of this cell's 12 edges: its own (edge set S, first slot sb) or the neighbour's
+            // that computes it -- 1, 5, 9 = the x neighbour's 3, 7, 8; 2, 6, 11 = the y neighbour's 0, 4, 8; 10 = the xy
+            // neighbour's 8, else the x neighbour's 11, else the y neighbour's 9.  Edge numbers are compile-time here:
+            // each slot is `first slot + popcount(edge set below the edge)`, two instructions.
+            const u32 owx = own[min((u32)lane + 1u, 63u)], owy = own[ny_lane], owxy = own[min(ny_lane + vy, 63u)];
+#define MC_SLOT(OW, E) ((((OW) >> 12) & 0xFFu) + (u32)__builtin_popcount((OW) & ((1u << (E)) - 1u)))
+#define MC_PICK(E, REMOTE) (((S >> (E)) & 1u) ? MC_SLOT(myow, E) : (REMOTE))
+            const u32 s10 = vxy ? MC_SLOT(owxy, 8) : vx ? MC_SLOT(owx, 11) : MC_SLOT(owy, 9);
+            const u32 sl0 = MC_SLOT(myow, 0) | (MC_PICK(1, MC_SLOT(owx, 3)) << 8) | (MC_PICK(2, MC_SLOT(owy, 0)) << 16) | (MC_SLOT(myow, 3) << 24);
+            const u32 sl1 = MC_SLOT(myow, 4) | (MC_PICK(5, MC_SLOT(owx, 7)) << 8) | (MC_PICK(6, MC_SLOT(owy, 4)) << 16) | (MC_SLOT(myow, 7) << 24);
+            const u32 sl2 = MC_SLOT(myow, 8) | (MC_PICK(9, MC_SLOT(owx, 8)) << 8) | (MC_PICK(10, s10) << 16) | (MC_PICK(11, MC_SLOT(owy, 8)) << 24);
+#undef MC_PICK
+#undef MC_SLOT
+            const u32 rowi = ((rec >> 16) & 1u) ? 255u - code : code;  // marching.cpp:542-547
+            const u64 trow = c_tri_row[rowi];
+            for (u32 t = 0; t < nt; ++t) {
+                const u32 tri12 = (u32)(trow >> (12u * t)) & 0xFFFu;  // the triangle's three edges (marching.cpp:586-594)
+                u32 ent = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const u32 e = (tri12 >> (4 * k)) & 0xFu;
+                    const u32 pack = e < 4u ? sl0 : e < 8u ? sl1 : sl2;
+                    const u32 slot = (pack >> (8u * (e & 3u))) & 0xFFu;
+                    // an edge the table walks downwards (2, 3, 6, 7: x, y, x, y) takes its axis coordinate from p_down
+                    const u32 dir = ((MC_EDGE_DOWN >> e) & 1u) ? (e & 1u) : 3u;
+                    ent |= (slot << (8 * k)) | (dir << (24 + 2 * k));
+                }
+                list[gtri0 - first + t] = ent;
+            }
+        }
+
+        // The next chunk's records are fetched NOW: vmcnt retires in order, so a load issued behind this chunk's vertex
+        // stores (phase D) would wait until they have all landed; issued here its latency hides under phase C, and the
+        // wait for it in front of D finds the previous chunk's stores long gone.
+        const u32 rn = r0 + nvalid + (u32)lane;
+        const u32 lo_n = find_segment(rn);
+        u32 rec_n = 0u;
+        if (rn < nrec) rec_n = recs[rbase[lo_n] + (rn - actoff[lo_n])];
+
+        // ---- C. one lane per computed vertex
+        for (u32 i0 = 0; i0 < M; i0 += 64u) {
+            const u32 i = i0 + (u32)lane;
+            if (i < M) {
+                const u32 it = item[i];
+                const int e = (int)(it >> 6);
+                const u32 rw = recw[it & 63u];
+                const u32 s2 = segrec[rw & 63u];
+                const int bx = (int)(((s2 >> 22) & 7u) * (u32)MC_SEG + ((rw >> 6) & 0xFFu)) + (int)((MC_EDGE_OX >> e) & 1u);
+                const int by = (int)(s2 & 2047u) + (int)((MC_EDGE_OY >> e) & 1u);
+                const int bz = (int)((s2 >> 11) & 2047u) + (int)((MC_EDGE_OZ >> e) & 1u);
+                const int ax = edge_axis(e);
+                const float x0 = axis[bx], y0 = axis[by], z0 = axis[bz];
+                const float c0 = ax == 0 ? x0 : ax == 1 ? y0 : z0;              // the edge's lower end on its axis
+                const float c1 = axis[(ax == 0 ? bx : ax == 1 ? by : bz) + 1];  // ... its upper end
+                const float x1 = ax == 0 ? c1 : x0, y1 = ax == 1 ? c1 : y0, z1 = ax == 2 ? c1 : z0;
+                // the same mc_F, the same operands as the classification of the two corners (marching.cpp:475-479)
+                const float v0 = mc_F(p, x0, y0, z0), v1 = mc_F(p, x1, y1, z1);
+                const float pu = mc_interp(iso, c0, c1, v0, v1);  // marching.cpp:557-583 for an edge walked upwards
+                const float pd = mc_interp(iso, c1, c0, v1, v0);  // ... downwards (edges 2, 3, 6, 7)
+                // the two other coordinates are lattice coordinates (x_s + t*0 in the reference)
+                const float qx = ax == 0 ? pu : x0, qy = ax == 1 ? pu : y0, qz = ax == 2 ? pu : z0;
+                float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+                if (want_normals && !mc_grad_normal(p, qx, qy, qz, h, nx, ny, nz)) nx = __builtin_nanf("");  // marker: see D
+                float4* o = (float4*)(vc + 8u * i);
+                o[0] = make_float4(qx, qy, qz, pd);
+                o[1] = make_float4(nx, ny, nz, 0.0f);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec_n)::"memory");  // the prefetched records, before the first store of D
+        // ---- D. one lane per output vertex
+        const u32 nverts = 3u * chunk_t;
+        const u64 room = cap_tris > (u64)first ? (cap_tris - (u64)first) * 72ull : 0ull;  // bytes of the vertex array from `first` on
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(verts + (u64)first * 18ull, 0, (int)(room < 0x7FFFFFF0ull ? room : 0x7FFFFFF0ull), 0x00020000);
+        for (u32 v0 = 0; v0 < nverts; v0 += 64u) {
+            const u32 vid = v0 + (u32)lane;
+            if (vid < nverts) {
+                const u32 tri = vid / 3u;
+                const int k = (int)(vid - 3u * tri);
+                const u32 ent = list[tri];
+                const u32 slot = (ent >> (8 * k)) & 0xFFu, dir = (ent >> (24 + 2 * k)) & 3u;
+                const float4 a = ((const float4*)vc)[2u * slot], b = ((const float4*)vc)[2u * slot + 1u];
+                const float qx = dir == 0u ? a.w : a.x, qy = dir == 1u ? a.w : a.y, qz = dir == 2u ? a.w : a.z;
+                float nx = b.x, ny = b.y, nz = b.z;
+                if (nx != nx) {  // degenerate gradient: the triangle's own normal cross(B-A, C-A)
+                    float px[3], py[3], pz[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float4 q = ((const float4*)vc)[2u * ((ent >> (8 * c)) & 0xFFu)];
+                        const u32 d = (ent >> (24 + 2 * c)) & 3u;
+                        px[c] = d == 0u ? q.w : q.x;
+                        py[c] = d == 1u ? q.w : q.y;
+                        pz[c] = d == 2u ? q.w : q.z;
+                    }
+                    const float e1x = px[1] - px[0], e1y = py[1] - py[0], e1z = pz[1] - pz[0];
+                    const float e2x = px[2] - px[0], e2y = py[2] - py[0], e2z = pz[2] - pz[0];
+                    const float cxn = e1y * e2z - e1z * e2y;
+                    const float cyn = e1z * e2x - e1x * e2z;
+                    const float czn = e1x * e2y - e1y * e2x;
+                    const float l = __builtin_sqrtf((cxn * cxn + cyn * cyn) + czn * czn);
+                    nx = ny = nz = 0.0f;
+                    if (l > 0.0f && !__builtin_isinf(l)) {
+                        const float inv = 1.0f / l;
+                        nx = cxn * inv;
+                        ny = cyn * inv;
+                        nz = czn * inv;
+                    }
+                }
+                // 24 bytes per vertex through a buffer descriptor over the chunk's part of the vertex array: a scalar base
+                // and a 32-bit lane offset (no 64-bit address arithmetic per lane), and the hardware's range check drops
+                // what lies beyond the buffer's capacity (the host then grows it and sweeps again)
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x4 s0;
+                s0.x = qx; s0.y = qy; s0.z = qz; s0.w = nx;
+                f32x2 s1;
+                s1.x = ny; s1.y = nz;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), vrsrc, vid * 24u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, s1), vrsrc, vid * 24u + 16u, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        r0 += nvalid;
+        lo = lo_n;
+        rec = rec_n;
+    }
+}
+
 struct McVert {
     float x, y, z;
 };
@@ -1095,10 +1377,10 @@ struct McVert {
 // marching.cpp:557-583 (edge interpolation from corner v1 to corner v2 of the edge table) with
 // Marching::interp (:437-446) applied to x, y and z.  The reference evaluates the quotient
 // (iso - v_s)/(v_e - v_s) once per axis with identical operands; it is computed once here.
-// The fallback `x_s + 0.5*(x_e - x_s)` is evaluated in double by the reference; one add of two
-// floats rounded to double and then to float equals the float add (53 >= 2*24+2).
+// qn: the same intersection seen from the lattice edge's LOWER end -- for the edges the table walks upwards the point
+// itself, for edges 2, 3, 6, 7 it can differ in the last bit -- which is where DESIGN.md N1 takes the normal.
 __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_axis, const u64* s_row, const u8* s_edge,
-                                            int row, int slot, int ix, int iy, int iz) {
+                                            int row, int slot, int ix, int iy, int iz, McVert& qn) {
     const int edge = (int)((s_row[row] >> (4 * slot)) & 0xF);
     const int ec = s_edge[edge];
     const int v1 = ec & 0xF, v2 = ec >> 4;
@@ -1114,9 +1396,16 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
     r.x = (__builtin_isinf(vx) || __builtin_isnan(vx)) ? xs + 0.5f * dx : xs + vx;
     r.y = (__builtin_isinf(vy) || __builtin_isnan(vy)) ? ys + 0.5f * dy : ys + vy;
     r.z = (__builtin_isinf(vz) || __builtin_isnan(vz)) ? zs + 0.5f * dz : zs + vz;
+    qn = r;
+    if ((MC_EDGE_DOWN >> edge) & 1u) {  // an x or y edge walked from its upper to its lower end
+        if (edge & 1) qn.y = mc_interp(p.iso, ye, ys, ve, vs);
+        else qn.x = mc_interp(p.iso, xe, xs, ve, vs);
+    }
     return r;
 }
 
+// mc_emit_direct -- the emit kernel for CHEAP f (mc_runtime picks it when f costs less than the bookkeeping that
+// sharing a vertex between its ~6 output copies needs: measured).
 // One wave = one GROUP of 64 consecutive segments.  Phase 1, one lane per RECORD (= active
 // cell, written by mc_classify): find the owning segment by binary search over the group's
 // active-cell offsets (LDS), read the record, and expand its triangles into 4-byte work items
@@ -1124,9 +1413,9 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
 // Phase 2, one lane per output VERTEX: edge lookup (nibble-packed table row in LDS), two corner
 // evaluations, the interpolation, the central-difference gradient of f for the normal, 24-byte
 // store.
-extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
-                                                                     float* __restrict__ verts, unsigned short* __restrict__ trimeta) {
+                                                                     float* __restrict__ verts) {
     __shared__ u64 s_row[256];
     __shared__ u8 s_edge[16];
     __shared__ u32 s_list[MC_WPB_E][MC_LIST_CAP];
@@ -1211,7 +1500,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
     }
     const float h = 0.5f * p.step;
     const bool want_normals = (p.flags & 1u) != 0u;
-    const bool want_meta = (p.flags & 16u) != 0u && trimeta != nullptr;
 
     u32 nlist = 0;                                             // triangles staged
     u32 listbase = (u32)__builtin_amdgcn_readfirstlane((int)o0.x);  // global index of list[0]
@@ -1220,11 +1508,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#ifdef MC_DBG_EMIT_NOFLUSH
-        const u32 nverts = 0;
-#else
         const u32 nverts = 3u * nlist;
-#endif
         for (u32 v0 = 0; v0 < nverts; v0 += 64u) {
             const u32 vid = v0 + (u32)lane;
             if (vid < nverts) {
@@ -1238,13 +1522,14 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
                 const int t = (int)((e >> 23) & 7u);
                 const int iy = (int)(sr & 2047u), iz = (int)((sr >> 11) & 2047u);
                 const int ix = (int)(sr >> 22) * MC_SEG + cellx;
-                const McVert q = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + k, ix, iy, iz);
+                McVert qn;  // where the normal is taken: the edge's intersection point seen from its LOWER end
+                const McVert q = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + k, ix, iy, iz, qn);
                 float nx = 0.0f, ny = 0.0f, nz = 0.0f;
                 if (want_normals) {
-                    // n = g/|g|, g = central difference of F at the vertex, h = step/2
-                    const float gx = mc_F(p, q.x + h, q.y, q.z) - mc_F(p, q.x - h, q.y, q.z);
-                    const float gy = mc_F(p, q.x, q.y + h, q.z) - mc_F(p, q.x, q.y - h, q.z);
-                    const float gz = mc_F(p, q.x, q.y, q.z + h) - mc_F(p, q.x, q.y, q.z - h);
+                    // n = g/|g|, g = central difference of F at that point, h = step/2
+                    const float gx = mc_F(p, qn.x + h, qn.y, qn.z) - mc_F(p, qn.x - h, qn.y, qn.z);
+                    const float gy = mc_F(p, qn.x, qn.y + h, qn.z) - mc_F(p, qn.x, qn.y - h, qn.z);
+                    const float gz = mc_F(p, qn.x, qn.y, qn.z + h) - mc_F(p, qn.x, qn.y, qn.z - h);
                     const float len2 = (gx * gx + gy * gy) + gz * gz;
                     const float len = __builtin_sqrtf(len2);
                     if (len2 >= 1e-30f && !__builtin_isinf(len2)) {
@@ -1260,9 +1545,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
                         ny = gy * inv;
                         nz = gz * inv;
                     } else {  // degenerate gradient: the triangle's own normal cross(B-A, C-A)
-                        const McVert a = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 0, ix, iy, iz);
-                        const McVert b = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 1, ix, iy, iz);
-                        const McVert c = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 2, ix, iy, iz);
+                        const McVert a = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 0, ix, iy, iz, qn);
+                        const McVert b = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 1, ix, iy, iz, qn);
+                        const McVert c = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 2, ix, iy, iz, qn);
                         const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
                         const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
                         const float cxn = e1y * e2z - e1z * e2y;
@@ -1278,32 +1563,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
                     }
                 }
                 const u64 gtri = (u64)listbase + tri;
-#ifdef MC_DBG_EMIT_NOSTORE
-                asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(nx), "v"(ny), "v"(nz));
-                if (false) {
-#else
                 if (gtri < p.cap_tris) {
-#endif
                     // three 8-byte stores per vertex.  (Staging the iteration's 1536 contiguous bytes
                     // in LDS and writing 16-byte pieces was measured slower: 0.31 vs 0.29 ms.)
                     float* o = verts + (gtri * 3ull + (u64)k) * 6ull;
-#ifdef MC_EMIT_STORE_X4
-                    typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-                    typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
-                    f4u a;
-                    a.x = q.x; a.y = q.y; a.z = q.z; a.w = nx;
-                    f2u b;
-                    b.x = ny; b.y = nz;
-                    *(f4u*)o = a;
-                    *(f2u*)(o + 4) = b;
-#else
                     ((float2*)o)[0] = make_float2(q.x, q.y);
                     ((float2*)o)[1] = make_float2(q.z, nx);
                     ((float2*)o)[2] = make_float2(ny, nz);
-#endif
-                    // optional (MC_FLAG_TRI_META): table row actually used | triangle number inside its
-                    // cell << 8, so a host can rebuild the reference's per-cell, per-edge vertex order
-                    if (want_meta && k == 0) trimeta[gtri] = (unsigned short)(row | (t << 8));
                 }
             }
         }
@@ -1342,6 +1608,333 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit(const McPara
         nlist += chunk_t;
     }
     if (nlist) flush();
+    }
+}
+
+// =============================================================== indexed mesh (MC_FLAG_INDEXED)
+// Poly_Data as the reference builds it (marching.cpp:599-654): vertex_list / tri_list with the vertices welded.  The
+// reference welds through a std::set whose comparator calls two points equal when they are closer than 1e-6 on every
+// axis (marching.h:32-55); the first point inserted keeps its coordinates and its index.  Points of different cells
+// can only meet on a shared lattice edge or at a lattice corner, so the same mesh follows from a closed form
+// (tests/weld_model.py states it in Python and checks it against a replay of the std::set):
+//
+//   key(vertex)   = the lattice CORNER it sits on, when the intersection point of its lattice edge -- computed in the +axis
+//                   direction -- is closer than 1e-6 to an end of that edge; else the lattice EDGE itself
+//   owner(key)    = the first cell of the sweep (z, y, x) that produces a vertex with this key, and in that cell the
+//                   lowest-numbered such edge; the vertex keeps the position THAT cell computes for it
+//   index(vertex) = keys owned by earlier cells + rank of the key among the owner's own edges (edge order 0..11)
+//
+// mc_resolve evaluates owner(key) from lattice indices and at most 9 samples of f; the kernels below are three sweeps
+// over the records (one wave per group, lane = record, like mc_emit): mark the owned edges, number and write the
+// vertices, write the triangles' indices.
+__device__ __forceinline__ int mc_snap(float iso, float c0, float c1, float v0, float v1) {
+    const float pu = mc_interp(iso, c0, c1, v0, v1);
+    // marching.h:38-40 close_enough: float difference, compared as a double with 0.000001
+    if (__builtin_fabs((double)(pu - c0)) < 0.000001) return 1;  // sits on the lower end
+    if (__builtin_fabs((double)(pu - c1)) < 0.000001) return 2;  // ... on the upper end
+    return 0;
+}
+
+// a cell of this sweep that can hold vertices: inside the slab and -- with constraints -- not skipped (marching.cpp:476;
+// a skipped cell's code byte reads 0, and a cell that contains a crossed edge never has code 0 or 255 otherwise)
+__device__ __forceinline__ bool mc_cell_ok(const McParams& p, const u8* __restrict__ codes, int qx, int qy, int qz) {
+    if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.z_begin || qz >= p.z_begin + p.nz) return false;
+#ifdef MC_CONS
+    const u64 row = (u64)(qz - p.z_begin) * (u64)p.n1 + (u64)qy;
+    const u32 c = qx < p.main_cells ? (u32)codes[row * p.pitch + (u64)qx] : (p.codes_tail[row] >> (8 * (qx - p.main_cells))) & 0xFFu;
+    return c != 0u && c != 255u;
+#else
+    (void)codes;
+    return true;
+#endif
+}
+
+// edge number of the lattice edge along `ax` whose lower end sits at offsets (d0, d1) on the two other axes (in axis order)
+__device__ __forceinline__ int mc_edge_of(int ax, int d0, int d1) {
+    return ax == 0 ? 2 * d0 + 4 * d1 : ax == 1 ? 3 - 2 * d0 + 4 * d1 : 8 + (d1 ? 3 - d0 : d0);
+}
+
+// owner of the vertex on edge e of cell (ix, iy, iz): cell (qx, qy, qz) and its edge qe
+__device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, int ix, int iy, int iz, int e, int& qx, int& qy,
+                                           int& qz, int& qe) {
+    const float* __restrict__ axis = p.axis;
+    const int ax = edge_axis(e);
+    int b[3] = {ix + (int)((MC_EDGE_OX >> e) & 1u), iy + (int)((MC_EDGE_OY >> e) & 1u), iz + (int)((MC_EDGE_OZ >> e) & 1u)};
+    const float x0 = axis[b[0]], y0 = axis[b[1]], z0 = axis[b[2]];
+    const int ba = ax == 0 ? b[0] : ax == 1 ? b[1] : b[2];
+    const float c0 = axis[ba], c1 = axis[ba + 1];
+    const float v0 = mc_F(p, x0, y0, z0);
+    const float v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
+    const int sn = mc_snap(p.iso, c0, c1, v0, v1);
+    if (sn == 0) {
+        // lattice-edge key: the first of the (up to) four cells around the edge, in sweep order
+        const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
+#pragma unroll
+        for (int d1 = 1; d1 >= 0; --d1)
+#pragma unroll
+            for (int d0 = 1; d0 >= 0; --d0) {
+                int q[3] = {b[0], b[1], b[2]};
+                q[a0] -= d0;
+                q[a1] -= d1;
+                if (mc_cell_ok(p, codes, q[0], q[1], q[2])) {
+                    qx = q[0];
+                    qy = q[1];
+                    qz = q[2];
+                    qe = mc_edge_of(ax, d0, d1);
+                    return;
+                }
+            }
+        qx = ix; qy = iy; qz = iz; qe = e;  // not reached: the cell itself is one of the four
+        return;
+    }
+    // lattice-corner key C
+    int C[3] = {b[0], b[1], b[2]};
+    if (sn == 2) C[ax] += 1;
+    const float fc = sn == 1 ? v0 : v1;
+    const float cx = axis[C[0]], cy = axis[C[1]], cz = axis[C[2]];
+    // which of the six lattice edges at C carry an intersection that sits on C: bit 2a + da, da = 0 the edge towards
+    // +a (inside the cells whose offset from C on that axis is 0), da = 1 the edge towards -a
+    u32 Sm = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int da = 0; da < 2; ++da) {
+            const int n = C[a] + (da == 0 ? 1 : -1);
+            const int lo_lim = a == 2 ? p.z_begin : 0, hi_lim = a == 2 ? p.z_begin + p.nz : p.n1;
+            if (n < lo_lim || n > hi_lim) continue;  // no such sample in this sweep's lattice
+            const float cn = axis[n], cc = a == 0 ? cx : a == 1 ? cy : cz;
+            const float fn = mc_F(p, a == 0 ? cn : cx, a == 1 ? cn : cy, a == 2 ? cn : cz);
+            if ((fc > p.iso) == (fn > p.iso)) continue;
+            const float pu = da == 0 ? mc_interp(p.iso, cc, cn, fc, fn) : mc_interp(p.iso, cn, cc, fn, fc);
+            if (__builtin_fabs((double)(pu - cc)) < 0.000001) Sm |= 1u << (2 * a + da);
+        }
+#pragma unroll
+    for (int dz = 1; dz >= 0; --dz)
+#pragma unroll
+        for (int dy = 1; dy >= 0; --dy)
+#pragma unroll
+            for (int dx = 1; dx >= 0; --dx) {
+                // the cell C - (dx, dy, dz) holds, of C's six edges, the one towards -a where its offset is 1, towards +a where 0
+                const u32 mx = (Sm >> (0 + dx)) & 1u, my = (Sm >> (2 + dy)) & 1u, mz = (Sm >> (4 + dz)) & 1u;
+                if (!(mx | my | mz)) continue;
+                if (!mc_cell_ok(p, codes, C[0] - dx, C[1] - dy, C[2] - dz)) continue;
+                // their edge numbers in that cell (the lower end of an edge along a has offset 0 on a); lowest wins
+                int best = 12;
+                if (mx) best = min(best, mc_edge_of(0, dy, dz));
+                if (my) best = min(best, mc_edge_of(1, dx, dz));
+                if (mz) best = min(best, mc_edge_of(2, dx, dy));
+                qx = C[0] - dx;
+                qy = C[1] - dy;
+                qz = C[2] - dz;
+                qe = best;
+                return;
+            }
+    qx = ix; qy = iy; qz = iz; qe = e;  // not reached: the cell itself holds a snapping edge at C
+}
+
+// the group's segment tables for the sweeps over the records (same layout as in mc_emit)
+struct McGroup {
+    u32* segrec;  // iy | iz << 11 | chunk << 22
+    u32* actoff;  // exclusive active-cell offsets, [64] = total
+    u32* trioff;  // first triangle
+    u32* rbase;   // first record
+    u32 nrec;
+    u32 tri0;
+};
+__device__ __forceinline__ bool mc_group_setup(const McParams& p, const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff, u32 group,
+                                               int lane, McGroup& g) {
+    const u32 seg = group * 64u + (u32)lane;
+    const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
+    if (g0.y == g1.y) return false;
+    const uint2 cb = seg < p.nseg ? segcb[seg] : make_uint2(0u, 0u);
+    const u32 ctri = cb.x & 0xFFFFu, cact = cb.x >> 16;
+    const u32 itri = wave_inclusive_scan(ctri), iact = wave_inclusive_scan(cact);
+    g.nrec = (u32)__builtin_amdgcn_readlane((int)iact, 63);
+    g.tri0 = g0.x;
+    const u32 sg = min(seg, p.nseg - 1u);
+    const u32 rowidx = sg / (u32)p.nchunk;
+    const u32 ch = sg - rowidx * (u32)p.nchunk;
+    const u32 lz = rowidx / (u32)p.n1;
+    const u32 iy = rowidx - lz * (u32)p.n1;
+    g.segrec[lane] = iy | ((u32)(p.z_begin + (int)lz) << 11) | (ch << 22);
+    g.actoff[lane] = iact - cact;
+    g.trioff[lane] = g0.x + (itri - ctri);
+    g.rbase[lane] = cb.y;
+    if (lane == 63) g.actoff[64] = g.nrec;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+// record number r of the group: its index in recs, the record, its cell and first triangle
+__device__ __forceinline__ bool mc_group_record(const McGroup& g, const u32* __restrict__ recs, u32 r, u32& ridx, u32& rec, int& ix, int& iy,
+                                                int& iz, u32& gtri0) {
+    u32 lo = 0, hi = 64;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const u32 mid = (lo + hi) >> 1;
+        if (g.actoff[mid] <= r) lo = mid; else hi = mid;
+    }
+    const bool valid = r < g.nrec;
+    ridx = valid ? g.rbase[lo] + (r - g.actoff[lo]) : 0u;
+    rec = valid ? recs[ridx] : 0u;
+    const u32 sr = g.segrec[lo];
+    ix = (int)(((sr >> 22) & 7u) * (u32)MC_SEG + (rec & 0xFFu));
+    iy = (int)(sr & 2047u);
+    iz = (int)((sr >> 11) & 2047u);
+    gtri0 = g.trioff[lo] + (rec >> 20);
+    return valid;
+}
+
+#define MC_WPB_I 4  // waves per workgroup of the three indexing kernels (mc_runtime launches them with the same number)
+#define MC_GROUP_LDS                                                        \
+    __shared__ u32 s_seg[MC_WPB_I][64], s_act[MC_WPB_I][66], s_tri[MC_WPB_I][64], s_rb[MC_WPB_I][64]; \
+    const int lane = threadIdx.x & 63;                                      \
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
+    const McParams p = *P;                                                  \
+    const u32 ngroups = (p.nseg + 63u) / 64u;                               \
+    const u32 group = blockIdx.x * (u32)MC_WPB_I + (u32)w;                  \
+    if (group >= ngroups || p.rec_cursor[0] != 0u) return;                  \
+    McGroup g;                                                              \
+    g.segrec = s_seg[w];                                                    \
+    g.actoff = s_act[w];                                                    \
+    g.trioff = s_tri[w];                                                    \
+    g.rbase = s_rb[w];                                                      \
+    if (!mc_group_setup(p, segcb, grpoff, group, lane, g)) return;
+
+// I1: per record, the edges whose vertex this cell owns (first of the sweep to produce the key); per group, their number
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                                      const u8* __restrict__ codes, u32* __restrict__ recown,
+                                                                      u64* __restrict__ grpv) {
+    MC_GROUP_LDS
+    u32 total = 0;
+    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+        u32 ridx, rec, gtri0;
+        int ix, iy, iz;
+        const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
+        u32 ownm = 0;
+        if (valid) {
+            u32 m = crossed_edges((rec >> 8) & 0xFFu);
+            while (m) {
+                const int e = __builtin_ctz(m);
+                m &= m - 1u;
+                int qx, qy, qz, qe;
+                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe);
+                if (qx == ix && qy == iy && qz == iz && qe == e) ownm |= 1u << e;
+            }
+            recown[ridx] = ownm;
+        }
+        total += (u32)__builtin_popcount(ownm);
+    }
+    const u32 sum = wave_inclusive_scan(total);
+    if (lane == 63) grpv[group] = (u64)sum;
+}
+
+// I2: number the vertices (group offset from the scan + prefix over the group's records) and write the owned ones
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vwrite(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                       const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                                       const u32* __restrict__ recown, const uint2* __restrict__ grpvoff,
+                                                                       u32* __restrict__ recvb, float* __restrict__ vlist, u64 cap_verts) {
+    MC_GROUP_LDS
+    const float* __restrict__ axis = p.axis;
+    u32 carry = grpvoff[group].x;
+    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+        u32 ridx, rec, gtri0;
+        int ix, iy, iz;
+        const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
+        const u32 ownm = valid ? recown[ridx] : 0u;
+        const u32 c = (u32)__builtin_popcount(ownm);
+        const u32 incl = wave_inclusive_scan(c);
+        u32 vb = carry + incl - c;
+        carry += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (valid) {
+            recvb[ridx] = vb;
+            u32 m = ownm;
+            while (m) {
+                const int e = __builtin_ctz(m);
+                m &= m - 1u;
+                // the intersection point as THIS cell's edge direction computes it (marching.cpp:557-583)
+                const int bx = ix + (int)((MC_EDGE_OX >> e) & 1u), by = iy + (int)((MC_EDGE_OY >> e) & 1u), bz = iz + (int)((MC_EDGE_OZ >> e) & 1u);
+                const int ax = edge_axis(e);
+                const float x0 = axis[bx], y0 = axis[by], z0 = axis[bz];
+                const float c0 = ax == 0 ? x0 : ax == 1 ? y0 : z0;
+                const float c1 = axis[(ax == 0 ? bx : ax == 1 ? by : bz) + 1];
+                const float v0 = mc_F(p, x0, y0, z0);
+                const float v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
+                const float pa = ((MC_EDGE_DOWN >> e) & 1u) ? mc_interp(p.iso, c1, c0, v1, v0) : mc_interp(p.iso, c0, c1, v0, v1);
+                if ((u64)vb < cap_verts) {
+                    float* o = vlist + 3ull * vb;
+                    o[0] = ax == 0 ? pa : x0;
+                    o[1] = ax == 1 ? pa : y0;
+                    o[2] = ax == 2 ? pa : z0;
+                }
+                ++vb;
+            }
+        }
+    }
+}
+
+// the record of cell (qx, qy, qz): its segment's records are contiguous and ascending in x
+__device__ __forceinline__ u32 mc_find_record(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb, int qx, int qy,
+                                              int qz) {
+    const u32 seg = (u32)(((qz - p.z_begin) * p.n1 + qy) * p.nchunk + (qx >> 8));
+    const uint2 cb = segcb[seg];
+    u32 lo = cb.y, n = cb.x >> 16;
+    const u32 want = (u32)(qx & 255);
+    while (n > 1u) {  // lower bound
+        const u32 half = n >> 1;
+        if ((recs[lo + half - 1u] & 0xFFu) < want) {
+            lo += half;
+            n -= half;
+        } else {
+            n = half;
+        }
+    }
+    return lo;
+}
+
+// I3: tri_list -- for every triangle corner the index of its vertex (marching.cpp:618-624, :646-654)
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                       const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                                       const u8* __restrict__ codes, const u32* __restrict__ recown,
+                                                                       const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris) {
+    __shared__ u32 s_eidx[MC_WPB_I][64 * 13];  // per lane: the vertex index of each of its 12 edges (stride 13: no bank conflicts)
+    MC_GROUP_LDS
+    u32* eidx = s_eidx[w] + 13 * lane;
+    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+        u32 ridx, rec, gtri0;
+        int ix, iy, iz;
+        const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
+        if (valid) {
+            const u32 code = (rec >> 8) & 0xFFu;
+            const u32 myown = recown[ridx], myvb = recvb[ridx];
+            u32 m = crossed_edges(code);
+            while (m) {
+                const int e = __builtin_ctz(m);
+                m &= m - 1u;
+                int qx, qy, qz, qe;
+                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe);
+                u32 o = myown, vb = myvb;
+                if (!(qx == ix && qy == iy && qz == iz)) {
+                    const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
+                    o = recown[q];
+                    vb = recvb[q];
+                }
+                eidx[e] = vb + (u32)__builtin_popcount(o & ((1u << qe) - 1u));
+            }
+            const u32 row = ((rec >> 16) & 1u) ? 255u - code : code;  // marching.cpp:542-547
+            const u64 tr = c_tri_row[row];
+            const u32 nt = (rec >> 17) & 7u;
+            for (u32 t = 0; t < nt; ++t) {
+                const u64 gt = (u64)gtri0 + t;
+                if (gt < cap_tris) {
+                    u32* o = tlist + 3ull * gt;
+                    o[0] = eidx[(tr >> (12u * t)) & 0xFull];
+                    o[1] = eidx[(tr >> (12u * t + 4u)) & 0xFull];
+                    o[2] = eidx[(tr >> (12u * t + 8u)) & 0xFull];
+                }
+            }
+        }
     }
 }
 

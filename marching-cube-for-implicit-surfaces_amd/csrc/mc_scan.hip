@@ -19,70 +19,164 @@ typedef unsigned char u8;
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
 
-// grpsum[i] = triangles | active cells << 32 per group.  Three small launches turn it into
-// grpoff[i] = exclusive {triangle, active} offsets (u32) plus 64-bit totals.
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_reduce(const u64* __restrict__ segcnt, u32 nseg,
-                                                             uint2* __restrict__ blocksum) {
-    typedef hipcub::BlockReduce<u64, SCAN_BLOCK> Reduce;
-    __shared__ typename Reduce::TempStorage tmp;
-    const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    u64 acc = 0;  // tris in the low half, active cells in the high half
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < nseg) acc += segcnt[base + i];
-    const u64 tot = Reduce(tmp).Sum(acc);
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = make_uint2((u32)tot, (u32)(tot >> 32));
-}
-
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_blocks(const uint2* __restrict__ blocksum, u32 nblocks,
-                                                             ulonglong2* __restrict__ blockoff, u64* __restrict__ totals,
-                                                             uint2* __restrict__ segoff_last) {
+// grpsum[i] = triangles | active cells << 32 per group  ->  grpoff[i] = exclusive {triangle, active} offsets (u32) plus
+// 64-bit totals, in ONE launch: a single-pass scan with decoupled look-back.  (Three launches -- reduce, scan of the block
+// sums, final -- cost 13 us per sweep at 1025^3, mostly launch boundaries: a tenth of a slab's sweep once the grid is
+// sharded over 8 GPUs.)
+//
+// Every workgroup takes a ticket (so that all workgroups with a lower number have started, whatever the dispatch order),
+// reduces its tile of SCAN_TILE groups, publishes the tile's AGGREGATE, looks back over its predecessors -- one wave, 64
+// predecessors per step -- until it meets one whose INCLUSIVE prefix is known, publishes its own inclusive prefix and
+// scans its tile.  A status entry is two 8-byte words {state << 62 | triangles, state << 62 | active cells}, each
+// written by one agent-scope store (the value travels with its tag: no fence, MI355X_MICROARCH.md "granule"); a reader
+// accepts a pair only when both words carry the same non-zero state (the words are written in order, first to second,
+// and read in the same order, so a torn pair shows two different states).  `status`, `ticket` and `totals` are zeroed
+// by the host's memset node before every sweep.  Spins are bounded: a workgroup that gives up raises totals[3] (the
+// host reads totals[3] from the device copy only when the counts look wrong -- it cannot happen while every workgroup
+// with a lower ticket is running, which the ticket order guarantees).
+#define SCAN_AGG 1ull
+#define SCAN_INC 2ull
+#define SCAN_SPIN_MAX (1u << 24)
+extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(const u64* __restrict__ grpsum, u32 n, uint2* __restrict__ grpoff,
+                                                              u64* __restrict__ totals, u64* status, u32* ticket,
+                                                              const u32* __restrict__ overflow_word, u64* __restrict__ totals_host) {
     typedef hipcub::BlockScan<u64, SCAN_BLOCK> Scan;
     __shared__ typename Scan::TempStorage tmp;
-    u64 carry_t = 0, carry_a = 0;
-    for (u32 b0 = 0; b0 < nblocks; b0 += SCAN_BLOCK) {
-        const u32 b = b0 + threadIdx.x;
-        const uint2 v = b < nblocks ? blocksum[b] : make_uint2(0, 0);
-        u64 et, ea, tt, ta;
-        Scan(tmp).ExclusiveSum((u64)v.x, et, tt);
-        __syncthreads();
-        Scan(tmp).ExclusiveSum((u64)v.y, ea, ta);
-        __syncthreads();
-        if (b < nblocks) blockoff[b] = make_ulonglong2(carry_t + et, carry_a + ea);
-        carry_t += tt;
-        carry_a += ta;
-    }
-    if (threadIdx.x == 0) {
-        totals[0] = carry_t;
-        totals[1] = carry_a;
-        *segoff_last = make_uint2((u32)carry_t, (u32)carry_a);
-    }
-}
-
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_final(const u64* __restrict__ segcnt, u32 nseg,
-                                                            const ulonglong2* __restrict__ blockoff,
-                                                            uint2* __restrict__ segoff) {
-    typedef hipcub::BlockScan<u64, SCAN_BLOCK> Scan;
-    __shared__ typename Scan::TempStorage tmp;
-    const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    __shared__ u32 s_bid;
+    __shared__ u64 s_pre[2];
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 b = s_bid;
+    const u32 base = b * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     u64 item[SCAN_ITEMS];
-    u64 sum = 0;
+    u64 sum = 0;  // inside one tile both halves fit 32 bits: 2048 groups * 64 segments * (1280 triangles | 256 cells)
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         u64 v = 0;
-        if (base + i < nseg) v = segcnt[base + i];
+        if (base + i < n) v = grpsum[base + i];
         item[i] = sum;  // exclusive within the thread
         sum += v;
     }
-    u64 excl;
-    Scan(tmp).ExclusiveSum(sum, excl);
-    const ulonglong2 bo = blockoff[blockIdx.x];
-    const u64 bt = bo.x + (excl & 0xFFFFFFFFull);
-    const u64 ba = bo.y + (excl >> 32);
+    u64 excl, agg;
+    Scan(tmp).ExclusiveSum(sum, excl, agg);
+    const u64 agg_t = agg & 0xFFFFFFFFull, agg_a = agg >> 32;
+    if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
+        const int lane = (int)threadIdx.x;
+        u64 pre_t = 0, pre_a = 0;
+        if (b == 0) {
+            if (lane == 0) {
+                __hip_atomic_store(&status[0], (SCAN_INC << 62) | agg_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&status[1], (SCAN_INC << 62) | agg_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (lane == 0) {
+                __hip_atomic_store(&status[2 * b], (SCAN_AGG << 62) | agg_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&status[2 * b + 1], (SCAN_AGG << 62) | agg_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int j0 = (int)b - 1;  // lane l looks at workgroup j0 - l
+            bool done = false, failed = false;
+            while (!done) {
+                const int j = j0 - lane;
+                u64 w0 = 0, w1 = 0;
+                if (j >= 0) {
+                    u32 spins = 0;
+                    for (;;) {
+                        w0 = __hip_atomic_load(&status[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w1 = __hip_atomic_load(&status[2 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((w0 >> 62) != 0ull && (w0 >> 62) == (w1 >> 62)) break;
+                        if (++spins > SCAN_SPIN_MAX) {
+                            failed = true;
+                            w0 = w1 = SCAN_INC << 62;  // give up: stop the walk here
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                } else {
+                    w0 = w1 = SCAN_INC << 62;  // before the first workgroup: an inclusive prefix of zero
+                }
+                const u64 incm = __ballot((w0 >> 62) == SCAN_INC);
+                // sum the lanes up to and including the first one that holds an inclusive prefix
+                const int stop = incm ? __builtin_ctzll(incm) : 63;
+                const bool take = lane <= stop;
+                u64 vt = take ? (w0 & 0x3FFFFFFFFFFFFFFFull) : 0ull, va = take ? (w1 & 0x3FFFFFFFFFFFFFFFull) : 0ull;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    vt += __shfl_xor(vt, o, 64);
+                    va += __shfl_xor(va, o, 64);
+                }
+                pre_t += vt;
+                pre_a += va;
+                done = incm != 0ull;
+                j0 -= 64;
+            }
+            if (__ballot(failed) && lane == 0) {
+                totals[3] = 1ull;
+                if (totals_host) totals_host[3] = 1ull;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&status[2 * b], (SCAN_INC << 62) | (pre_t + agg_t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&status[2 * b + 1], (SCAN_INC << 62) | (pre_a + agg_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lane == 0) {
+            s_pre[0] = pre_t;
+            s_pre[1] = pre_a;
+            if (b == gridDim.x - 1u) {
+                // totals: {triangles, active cells, mc_classify's "a record region overflowed" word, scan gave up};
+                // mirrored into pinned host memory so that the host needs no copy node behind the sweep
+                const u64 ovf = overflow_word ? (u64)overflow_word[0] : 0ull;
+                totals[0] = pre_t + agg_t;
+                totals[1] = pre_a + agg_a;
+                totals[2] = ovf;
+                grpoff[n] = make_uint2((u32)(pre_t + agg_t), (u32)(pre_a + agg_a));
+                if (totals_host) {
+                    totals_host[0] = pre_t + agg_t;
+                    totals_host[1] = pre_a + agg_a;
+                    totals_host[2] = ovf;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const u64 bt = s_pre[0] + (excl & 0xFFFFFFFFull);
+    const u64 ba = s_pre[1] + (excl >> 32);
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < nseg)
-            segoff[base + i] = make_uint2((u32)(bt + (item[i] & 0xFFFFFFFFull)), (u32)(ba + (item[i] >> 32)));
+        if (base + i < n) grpoff[base + i] = make_uint2((u32)(bt + (item[i] & 0xFFFFFFFFull)), (u32)(ba + (item[i] >> 32)));
+}
+
+// ---- indexed mesh: CalculateNormal (Source/normal.h:3-41) on the welded mesh.  Per triangle cross(B-A, C-A) in glm's
+// operation order, added to its three vertices; then every vertex normal * (1 / sqrt(dot)).  The reference adds in
+// triangle order, the atomics here in arrival order: same sums up to float rounding (a tolerance quantity; a vertex
+// without triangles, or with a zero sum, comes out NaN exactly as it does there).
+extern "C" __global__ __launch_bounds__(256) void mc_nrm_accum(const float* __restrict__ vlist, const u32* __restrict__ tlist, u64 ntris,
+                                                    u64 nverts, float* __restrict__ nacc) {
+    const u64 t = (u64)blockIdx.x * 256ull + threadIdx.x;
+    if (t >= ntris) return;
+    const u32 i1 = tlist[3 * t], i2 = tlist[3 * t + 1], i3 = tlist[3 * t + 2];
+    if (i1 >= nverts || i2 >= nverts || i3 >= nverts) return;
+    const float ax = vlist[3ull * i1], ay = vlist[3ull * i1 + 1], az = vlist[3ull * i1 + 2];
+    const float bax = vlist[3ull * i2] - ax, bay = vlist[3ull * i2 + 1] - ay, baz = vlist[3ull * i2 + 2] - az;
+    const float cax = vlist[3ull * i3] - ax, cay = vlist[3ull * i3 + 1] - ay, caz = vlist[3ull * i3 + 2] - az;
+    const float nx = bay * caz - cay * baz, ny = baz * cax - caz * bax, nz = bax * cay - cax * bay;
+    const u32 idx[3] = {i1, i2, i3};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsafeAtomicAdd(&nacc[3ull * idx[k]], nx);
+        unsafeAtomicAdd(&nacc[3ull * idx[k] + 1], ny);
+        unsafeAtomicAdd(&nacc[3ull * idx[k] + 2], nz);
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void mc_nrm_finish(float* __restrict__ nacc, u64 nverts) {
+    const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= nverts) return;
+    const float x = nacc[3 * i], y = nacc[3 * i + 1], z = nacc[3 * i + 2];
+    const float d = (x * x + y * y) + z * z;
+    const float inv = 1.0f / __builtin_sqrtf(d);
+    nacc[3 * i] = x * inv;
+    nacc[3 * i + 1] = y * inv;
+    nacc[3 * i + 2] = z * inv;
 }
 
 // positions only: verts[T*3][6] -> soup[T*3][3]

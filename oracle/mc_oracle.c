@@ -437,28 +437,28 @@ static int grad_normal(orc_ctx *c, const float p[3], float h, float n[3], int *o
     return 0;
 }
 
-/* marching.cpp:456-595 calculate_step for one cell; appends to the layer */
-static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float y0, float y1, float z0, float z1,
-                   uint8_t *code_out);
+/* marching.cpp:456-595 calculate_step for one cell, without the output side: cube code, the table row used after
+ * the ambiguity test (:519-549) and the intersection point of every crossed edge in edge order (:557-583).
+ * Returns 0, or -1 on evaluation underflow.  skipped = 1: a corner is outside a constraint (:476), nothing computed. */
+typedef struct {
+    int skipped, code, row, amb, flipped;
+    float val[8];
+    float ex[12], ey[12], ez[12]; /* NaN where the edge carries no intersection */
+} orc_cellcore;
 
-static int cell(orc_ctx *c, orc_layer *L, int want, const float *ax, int ix, int iy, int iz, uint8_t *code_out) {
-    return cell_at(c, L, want, ax[ix], ax[ix + 1], ax[iy], ax[iy + 1], ax[iz], ax[iz + 1], code_out);
-}
-
-/* calculate_step for the cell with lower corner (x0,y0,z0) and upper corner (x1,y1,z1): the dense sweep passes
- * lattice coordinates, seed mode passes x0 and x0 + step (marching.cpp:458-460) */
-static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float y0, float y1, float z0, float z1,
-                   uint8_t *code_out) {
+static int cell_core(orc_ctx *c, float x0, float x1, float y0, float y1, float z0, float z1, orc_cellcore *o) {
     /* :471-472 */
     const float cx[8] = {x0, x1, x1, x0, x0, x1, x1, x0};
     const float cy[8] = {y0, y0, y1, y1, y0, y0, y1, y1};
     const float cz[8] = {z0, z0, z0, z0, z1, z1, z1, z1};
-    float val[8];
+    float *val = o->val;
+    o->skipped = o->amb = o->flipped = 0;
+    o->code = o->row = 0;
     for (int i = 0; i < 8; i++) { /* :475-479: the first corner outside a constraint abandons the cell */
         if (c->ncons) {
             int w = within_constraints(c, cx[i], cy[i], cz[i]);
             if (w < 0) return -1;
-            if (!w) { *code_out = 0; return 0; } /* the reference writes nothing for such a cell; its code reads 0 here */
+            if (!w) { o->skipped = 1; return 0; } /* the reference writes nothing for such a cell; its code reads 0 here */
         }
         if (F(c, cx[i], cy[i], cz[i], &val[i])) return -1;
     }
@@ -466,14 +466,12 @@ static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float
     int code = 0; /* :497-505, strict > */
     for (int i = 0; i < 8; i++)
         if (val[i] > iso) code |= 1 << i;
-    *code_out = (uint8_t)code;
+    o->code = o->row = code;
     if (code == 0 || code == 255) return 0; /* :508-510 */
-    L->n_active++;
 
-    int row = code;
     int face = k_amb_face[code]; /* :523-549 */
     if (face != 0xFF) {
-        L->n_amb++;
+        o->amb = 1;
         float mx = 0, my = 0, mz = 0;
         for (int i = 0; i < 4; i++) {
             int vi = (k_face_corner[face] >> (4 * i)) & 0xF;
@@ -487,22 +485,37 @@ static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float
         float mid;
         if (F(c, mx, my, mz, &mid)) return -1;
         if (mid > iso) {
-            row = 255 - code;
-            L->n_flip++;
+            o->row = 255 - code;
+            o->flipped = 1;
         }
     }
 
-    float ex[12], ey[12], ez[12]; /* :557-583 */
-    for (int e = 0; e < 12; e++) {
+    for (int e = 0; e < 12; e++) { /* :557-583 */
         int v1 = k_edge_corner[e] & 0xF, v2 = k_edge_corner[e] >> 4;
         if (((code >> v1) & 1) != ((code >> v2) & 1)) {
-            ex[e] = interp(iso, cx[v1], cx[v2], val[v1], val[v2]);
-            ey[e] = interp(iso, cy[v1], cy[v2], val[v1], val[v2]);
-            ez[e] = interp(iso, cz[v1], cz[v2], val[v1], val[v2]);
+            o->ex[e] = interp(iso, cx[v1], cx[v2], val[v1], val[v2]);
+            o->ey[e] = interp(iso, cy[v1], cy[v2], val[v1], val[v2]);
+            o->ez[e] = interp(iso, cz[v1], cz[v2], val[v1], val[v2]);
         } else {
-            ex[e] = ey[e] = ez[e] = NAN;
+            o->ex[e] = o->ey[e] = o->ez[e] = NAN;
         }
     }
+    return 0;
+}
+
+/* calculate_step for the cell with lower corner (x0,y0,z0) and upper corner (x1,y1,z1), appended to the layer: the
+ * dense sweep passes lattice coordinates, seed mode passes x0 and x0 + step (marching.cpp:458-460) */
+static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float y0, float y1, float z0, float z1,
+                   uint8_t *code_out) {
+    orc_cellcore o;
+    if (cell_core(c, x0, x1, y0, y1, z0, z1, &o)) return -1;
+    *code_out = (uint8_t)o.code;
+    if (o.skipped || o.code == 0 || o.code == 255) return 0;
+    L->n_active++;
+    L->n_amb += (uint64_t)o.amb;
+    L->n_flip += (uint64_t)o.flipped;
+    const int code = o.code, row = o.row;
+    const float iso = c->iso;
 
     int nt = k_tri_count[row]; /* :586-594 */
     if (!(want & (ORC_WANT_SOUP | ORC_WANT_NORMALS))) {
@@ -510,24 +523,47 @@ static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float
         return 0;
     }
     if (layer_reserve(L, (size_t)nt, want)) return -4;
-    const float h = 0.5f * c->step;
+    /* ONE normal per crossed lattice edge, the gradient of F at the edge's intersection point computed in
+     * the edge's +axis direction (from its lower to its upper end).  For the edges the table walks upwards (0, 1, 4, 5,
+     * 8..11) that is the emitted point itself; edges 2, 3, 6, 7 run downwards and their emitted point can differ from it
+     * in the last bit.  Every cell that shares the lattice edge therefore gets the same normal bits. */
+    float en[12][3];
+    int eok[12];
+    if (want & ORC_WANT_NORMALS) {
+        const float cx[8] = {x0, x1, x1, x0, x0, x1, x1, x0};
+        const float cy[8] = {y0, y0, y1, y1, y0, y0, y1, y1};
+        const float cz[8] = {z0, z0, z0, z0, z1, z1, z1, z1};
+        const float h = 0.5f * c->step;
+        for (int e = 0; e < 12; e++) {
+            int v1 = k_edge_corner[e] & 0xF, v2 = k_edge_corner[e] >> 4;
+            eok[e] = 0;
+            if (((code >> v1) & 1) == ((code >> v2) & 1)) continue;
+            float p[3] = {o.ex[e], o.ey[e], o.ez[e]};
+            if (e == 2 || e == 3 || e == 6 || e == 7) { /* downward edge: the point seen from the lower end */
+                p[0] = interp(iso, cx[v2], cx[v1], o.val[v2], o.val[v1]);
+                p[1] = interp(iso, cy[v2], cy[v1], o.val[v2], o.val[v1]);
+                p[2] = interp(iso, cz[v2], cz[v1], o.val[v2], o.val[v1]);
+            }
+            if (grad_normal(c, p, h, en[e], &eok[e])) return -1;
+        }
+    }
     for (int t = 0; t < nt; t++) {
         float P[3][3];
+        int E[3];
         for (int k = 0; k < 3; k++) {
             int e = (int)((k_tri_row[row] >> (4 * (3 * t + k))) & 0xF);
-            P[k][0] = ex[e];
-            P[k][1] = ey[e];
-            P[k][2] = ez[e];
+            E[k] = e;
+            P[k][0] = o.ex[e];
+            P[k][1] = o.ey[e];
+            P[k][2] = o.ez[e];
         }
         if (want & ORC_WANT_SOUP) memcpy(L->soup + 9 * L->ntri, P, sizeof(P));
         if (want & ORC_WANT_NORMALS) {
             float fn[3] = {0, 0, 0};
             int have_fn = 0;
             for (int k = 0; k < 3; k++) {
-                float n[3];
-                int ok;
-                if (grad_normal(c, P[k], h, n, &ok)) return -1;
-                if (!ok) { /* fall back to the triangle's own normal cross(B-A, C-A) */
+                float n[3] = {en[E[k]][0], en[E[k]][1], en[E[k]][2]};
+                if (!eok[E[k]]) { /* fall back to the triangle's own normal cross(B-A, C-A) */
                     if (!have_fn) {
                         float e1[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
                         float e2[3] = {P[2][0] - P[0][0], P[2][1] - P[0][1], P[2][2] - P[0][2]};
@@ -552,6 +588,10 @@ static int cell_at(orc_ctx *c, orc_layer *L, int want, float x0, float x1, float
         L->ntri++;
     }
     return 0;
+}
+
+static int cell(orc_ctx *c, orc_layer *L, int want, const float *ax, int ix, int iy, int iz, uint8_t *code_out) {
+    return cell_at(c, L, want, ax[ix], ax[ix + 1], ax[iy], ax[iy + 1], ax[iz], ax[iz + 1], code_out);
 }
 
 void orc_mesh_free(orc_mesh *m) {
@@ -749,5 +789,97 @@ void orc_seed_finish(void *h, orc_mesh *out, uint64_t n_cells) {
     out->fnv_codes = FNV_OFFSET;
     stk_free(&s->c.stk);
     orc_expr_free(&s->e);
+    free(s);
+}
+
+/* ------------------------------------------------------------------ one cell at a time (Step_Data, marching.h:15-23)
+ * Per-cell back end of the indexed-mesh oracle (mc_oracle_weld.cpp): calculate_step for the cell with lattice indices
+ * (ix, iy, iz), handing back what add_step_to_poly_data (marching.cpp:599-625) consumes. */
+typedef struct {
+    orc_expr e;
+    orc_expr cexp[3];
+    orc_ctx c;
+    float *ax;
+    int n1;
+} orc_step_state;
+
+void *orc_step_begin(const char *eq, float step, float iso, const float scale[3], int pow_mode, const orc_constraint *cons,
+                     int ncons) {
+    if (!((double)step >= 0.001 && (double)step <= .5)) return NULL;
+    if (ncons < 0 || ncons > 3) return NULL;
+    orc_step_state *s = (orc_step_state *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    int ok = orc_tokenize(eq, &s->e);
+    int nc = 0;
+    for (; ok && nc < ncons; nc++)
+        if (cons[nc].op < ORC_CMP_GE || cons[nc].op > ORC_CMP_LT || !orc_tokenize(cons[nc].lhs, &s->cexp[nc])) break;
+    if (!ok || nc < ncons) {
+        if (ok) orc_expr_free(&s->e);
+        for (int k = 0; k < nc; k++) orc_expr_free(&s->cexp[k]);
+        free(s);
+        return NULL;
+    }
+    s->n1 = orc_cells_per_axis(step);
+    s->ax = (float *)malloc(((size_t)s->n1 + 1) * sizeof(float));
+    orc_axis_coords(step, s->ax, s->n1 + 1);
+    s->c.e = &s->e;
+    s->c.iso = iso;
+    s->c.step = step;
+    s->c.sx = scale[0];
+    s->c.sy = scale[1];
+    s->c.sz = scale[2];
+    s->c.ncons = ncons;
+    int bad = stk_init(&s->c.stk, &s->e, pow_mode);
+    for (int i = 0; i < ncons; i++) {
+        s->c.ce[i] = &s->cexp[i];
+        s->c.cop[i] = cons[i].op;
+        s->c.crhs[i] = cons[i].rhs;
+        bad |= stk_init(&s->c.cstk[i], &s->cexp[i], pow_mode);
+    }
+    if (bad) { orc_step_end(s); return NULL; }
+    return s;
+}
+
+int orc_step_cell(void *h, int ix, int iy, int iz, orc_step *out) {
+    orc_step_state *s = (orc_step_state *)h;
+    if (ix < 0 || iy < 0 || iz < 0 || ix >= s->n1 || iy >= s->n1 || iz >= s->n1) return -1;
+    const float *ax = s->ax;
+    orc_cellcore o;
+    if (cell_core(&s->c, ax[ix], ax[ix + 1], ax[iy], ax[iy + 1], ax[iz], ax[iz + 1], &o)) return -2;
+    memset(out, 0, sizeof(*out));
+    out->skipped = o.skipped;
+    out->code = o.code;
+    out->row = o.row;
+    if (o.skipped) return 0;
+    memcpy(out->val, o.val, sizeof(o.val));
+    if (o.code == 0 || o.code == 255) return 0;
+    int mapper[12]; /* :557-583: intersect_coord holds the crossed edges' points in edge order */
+    for (int e = 0; e < 12; e++) {
+        int v1 = k_edge_corner[e] & 0xF, v2 = k_edge_corner[e] >> 4;
+        mapper[e] = -1;
+        if (((o.code >> v1) & 1) != ((o.code >> v2) & 1)) {
+            mapper[e] = out->n_points;
+            out->edge[out->n_points] = e;
+            out->point[out->n_points][0] = o.ex[e];
+            out->point[out->n_points][1] = o.ey[e];
+            out->point[out->n_points][2] = o.ez[e];
+            out->n_points++;
+        }
+    }
+    out->n_tris = k_tri_count[o.row]; /* :586-594 */
+    for (int k = 0; k < 3 * out->n_tris; k++) out->tri_vlist[k] = mapper[(k_tri_row[o.row] >> (4 * k)) & 0xF];
+    return 0;
+}
+
+int orc_step_n1(void *h) { return ((orc_step_state *)h)->n1; }
+
+void orc_step_end(void *h) {
+    orc_step_state *s = (orc_step_state *)h;
+    if (!s) return;
+    stk_free(&s->c.stk);
+    for (int i = 0; i < s->c.ncons; i++) stk_free(&s->c.cstk[i]);
+    orc_expr_free(&s->e);
+    for (int i = 0; i < 3; i++) orc_expr_free(&s->cexp[i]);
+    free(s->ax);
     free(s);
 }

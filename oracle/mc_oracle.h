@@ -123,6 +123,37 @@ void *orc_seed_begin(const char *eq, float step, float iso, const float scale[3]
 int orc_seed_cell(void *h, float x0, float y0, float z0, uint8_t *code_out);
 void orc_seed_finish(void *h, orc_mesh *out, uint64_t n_cells);
 
+/* One cell at a time: calculate_step (marching.cpp:456-595) for the cell with lattice indices (ix, iy, iz), as the
+ * reference's Step_Data (marching.h:15-23) records it.  Back end of orc_march_indexed. */
+typedef struct {
+    int skipped;          /* a corner is outside a constraint (marching.cpp:476): nothing else is filled in */
+    int code, row;        /* cube code; table row used after the ambiguity test */
+    float val[8];         /* corner_values */
+    int n_points;         /* crossed edges */
+    int edge[12];         /* their edge numbers, ascending (edge_list) */
+    float point[12][3];   /* intersect_coord */
+    int n_tris;
+    int tri_vlist[15];    /* indices into point[] */
+} orc_step;
+void *orc_step_begin(const char *eq, float step, float iso, const float scale[3], int pow_mode, const orc_constraint *cons,
+                     int ncons);
+int orc_step_cell(void *h, int ix, int iy, int iz, orc_step *out); /* 0, -1 bad index, -2 evaluation underflow */
+int orc_step_n1(void *h);
+void orc_step_end(void *h);
+
+/* The reference's indexed mesh: Marching::add_step_to_poly_data / add_point / add_triangle (marching.cpp:599-654) over
+ * the full sweep (:372-383), welding through std::set<xyz> with the tolerance comparator of marching.h:32-55, and the
+ * drawer's CalculateNormal (normal.h:3-41) on the result.  z_begin/z_end as in orc_march (a slab is welded on its own). */
+typedef struct {
+    uint64_t n_verts, n_tris;
+    float *vertex_list;     /* 3 * n_verts */
+    uint32_t *tri_list;     /* 3 * n_tris (a NaN point keeps index -1, marching.cpp:611-613) */
+    float *normals;         /* 3 * n_verts, CalculateNormal */
+} orc_indexed;
+int orc_march_indexed(const char *eq, float step, float iso, const float scale[3], int pow_mode, const orc_constraint *cons,
+                      int ncons, int z_begin, int z_end, orc_indexed *out);
+void orc_indexed_free(orc_indexed *m);
+
 /* FNV-1a 64 (offset 1469598103934665603, prime 1099511628211), SURVEY.md section 4. */
 uint64_t orc_fnv1a(const void *p, size_t n, uint64_t h);
 

@@ -46,7 +46,7 @@ class _Mesh(C.Structure):
 def build(force=False):
     """Compile liboracle.so (and _ref/check_tables where the reference exists)."""
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / "mc_oracle.c", _HERE / "mc_oracle_seed.cpp", _HERE / "mc_oracle.h", _HERE.parent / "include" / "mc_tables_data.h",
+    srcs = [_HERE / "mc_oracle.c", _HERE / "mc_oracle_seed.cpp", _HERE / "mc_oracle_weld.cpp", _HERE / "mc_oracle.h", _HERE.parent / "include" / "mc_tables_data.h",
             _HERE.parent / "include" / "mc_trig.h"]
     if force or not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -209,4 +209,36 @@ def march(eq: str, step: float, iso: float = 0.0, scale=(1.0, 1.0, 1.0), pow_mod
     out.normals = (np.ctypeslib.as_array(m.normals, shape=(nt * 9,)).copy().reshape(nt, 3, 3)
                    if (want & WANT_NORMALS) and nt else np.zeros((0, 3, 3), np.float32) if (want & WANT_NORMALS) else None)
     lib().orc_mesh_free(C.byref(m))
+    return out
+
+
+class _Indexed(C.Structure):
+    _fields_ = [("n_verts", C.c_uint64), ("n_tris", C.c_uint64), ("vertex_list", C.POINTER(C.c_float)),
+                ("tri_list", C.POINTER(C.c_uint32)), ("normals", C.POINTER(C.c_float))]
+
+
+def march_indexed(eq: str, step: float, iso: float = 0.0, scale=(1.0, 1.0, 1.0), pow_mode=POW_LIBM, constraints=(),
+                  z_begin=0, z_end=-1) -> Mesh:
+    """The reference's indexed Poly_Data (marching.cpp:599-654: std::set welding in sweep order) plus the drawer's
+    CalculateNormal (normal.h).  Returns .vertices (V,3) f32, .tris (T,3) u32, .normals (V,3) f32."""
+    L = lib()
+    L.orc_march_indexed.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.c_int, C.POINTER(_Constraint),
+                                    C.c_int, C.c_int, C.c_int, C.POINTER(_Indexed)]
+    L.orc_march_indexed.restype = C.c_int
+    L.orc_indexed_free.argtypes = [C.POINTER(_Indexed)]
+    cons = (_Constraint * max(len(constraints), 1))()
+    for i, (lhs, op, rhs) in enumerate(constraints):
+        cons[i] = _Constraint(lhs.encode(), CMP[op], float(rhs))
+    m = _Indexed()
+    r = L.orc_march_indexed(eq.encode(), C.c_float(step), C.c_float(iso), (C.c_float * 3)(*scale), pow_mode, cons,
+                            len(constraints), z_begin, z_end, C.byref(m))
+    if r:
+        raise ValueError(f"orc_march_indexed failed ({r}) for {eq!r}")
+    out = Mesh()
+    nv, nt = m.n_verts, m.n_tris
+    out.n_verts, out.n_tris = nv, nt
+    out.vertices = np.ctypeslib.as_array(m.vertex_list, shape=(nv * 3,)).copy().reshape(nv, 3) if nv else np.zeros((0, 3), np.float32)
+    out.tris = np.ctypeslib.as_array(m.tri_list, shape=(nt * 3,)).copy().reshape(nt, 3) if nt else np.zeros((0, 3), np.uint32)
+    out.normals = np.ctypeslib.as_array(m.normals, shape=(nv * 3,)).copy().reshape(nv, 3) if nv else np.zeros((0, 3), np.float32)
+    L.orc_indexed_free(C.byref(m))
     return out

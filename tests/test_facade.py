@@ -18,6 +18,39 @@ def build_demo(mc):
     return EXE
 
 
+CALLER = ROOT / "tests" / "native" / "reference_caller"
+
+
+def build_caller(mc):
+    """tests/native/reference_caller.cpp: Source/main.cpp:11-14 + marching_test_drawer.h:7-15, its #include lines as they
+    are in the reference, compiled against include/compat."""
+    src = ROOT / "tests" / "native" / "reference_caller.cpp"
+    if not CALLER.exists() or CALLER.stat().st_mtime < max(src.stat().st_mtime, (ROOT / "include" / "mc_marching.hpp").stat().st_mtime,
+                                                            mc.LIB_PATH.stat().st_mtime):
+        subprocess.run(["g++", "-std=c++14", "-O1", f"-I{ROOT / 'include' / 'compat'}", str(src), "-o", str(CALLER),
+                        f"-L{mc.LIB_PATH.parent}", "-lmc_hip", f"-Wl,-rpath,{mc.LIB_PATH.parent}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return CALLER
+
+
+def test_reference_style_caller_compiles_with_only_the_include_path_changed(mc):
+    assert build_caller(mc).exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,verts,tris", [("x^2+y^2+z^2-1", 4758, 9548), ("x+y", 1122, 4290)])   # SURVEY.md section 4 counts
+def test_reference_style_caller_gets_the_reference_mesh(mc, orc, eq, verts, tris):
+    """Evaluator() / Marching() without arguments, evaluate(x, y, z), recalculate(), get_poly_data(), CalculateNormal(pData):
+    the welded mesh equals the oracle's replay of the reference's std::set welding, hash for hash."""
+    import numpy as np
+    r = subprocess.run([str(build_caller(mc)), eq], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = orc.march_indexed(eq, float(np.float32(2.0) / np.float32(32)), pow_mode=orc.POW_EXACT)
+    assert (ref.n_verts, ref.n_tris) == (verts, tris)
+    want = (f"verts={verts} tris={tris} fnv_vertex_list={orc.fnv1a(ref.vertices.tobytes()):016x} "
+            f"fnv_tri_list={orc.fnv1a(ref.tris.tobytes()):016x} normals={verts} ")
+    assert want in r.stdout, (r.stdout, want)
+
+
 def test_facade_compiles_and_links(mc):
     """A plain g++ caller needs only the two headers and libmc_hip.so (no HIP headers, no torch)."""
     assert build_demo(mc).exists()
@@ -57,7 +90,7 @@ def test_facade_matches_reference_fingerprints(mc, eq, n, iso, tris, fnv):
     ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 4, 0.0, 1.0, 0.0, 108, 148),
 ])
 def test_facade_indexed_mesh_matches_reference_counts(mc, eq, n, iso, scale, step, verts, tris):
-    """set_indexed(true): the reference's vertex welding (marching.cpp:599-654) replayed on the GPU soup."""
+    """set_indexed(true), the facade's default: the reference's vertex welding (marching.cpp:599-654) done on the GPU."""
     r = subprocess.run([str(build_demo(mc)), eq, str(n), str(iso), "indexed", str(scale), str(step)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"tris={tris} verts={verts} " in r.stdout, r.stdout

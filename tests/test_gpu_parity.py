@@ -45,6 +45,14 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
     if flags & mc.FLAG_NORMALS:
         d = np.abs(v[:, :, 3:] - o.normals)
         assert not d.size or np.nanmax(d) <= TOL_NRM, f"normals differ by {np.nanmax(d)}"
+    # both emit kernels (mc_emit_direct, the default for cheap f; mc_emit, which shares vertices inside a chunk, the default
+    # for expensive f) must write the same bytes
+    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED):
+        v2 = ctx.march(eq, step, iso, scale, flags | force, z[0], z[1]).vertices()
+        assert np.array_equal(u32(v2[:, :, :3]), u32(v[:, :, :3])), f"positions differ with emit flag {force}"
+        if flags & mc.FLAG_NORMALS:
+            ok = ~(np.isnan(v2[:, :, 3:]) & np.isnan(v[:, :, 3:]))
+            assert not ok.any() or np.abs(v2[:, :, 3:] - v[:, :, 3:])[ok].max() <= 1e-6, f"normals differ with emit flag {force}"
     return r, o
 
 
@@ -227,6 +235,44 @@ def test_graph_replay_equals_march(mc, ctx):
         ctx.graph_build(eq, step, iso=-0.4)
 
 
+def test_graph_survives_other_sweeps_on_its_context(mc, orc):
+    """A captured graph holds kernel handles, launch sizes and raw device pointers.  Sweeps of OTHER equations, grids and
+    scales on the same context (which re-target the axis tables and re-allocate buffers), and constraint changes, must
+    not make a later replay run one equation's kernels over another's buffers: the replay re-captures its own sweep."""
+    c = mc.Context(0)
+    try:
+        eq, step = EQ["goursat"], step_of(48)
+        want = {iso: orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=2) for iso in (-0.4, -0.2)}
+        c.graph_build(eq, step, iso=-0.4)
+        c.march(EQ["sphere"], step_of(200))                       # larger grid: every buffer is re-allocated
+        g = c.graph_replay(-0.2)
+        assert_same_floats(g.vertices()[:, :, :3], want[-0.2].soup, "after a larger sweep")
+        c.march(EQ["eq3"], step_of(48), scale=(1.1, 1.1, 1.1))    # same size, other equation and axis tables
+        g = c.graph_replay(-0.4)
+        assert_same_floats(g.vertices()[:, :, :3], want[-0.4].soup, "after another equation")
+        c.set_constraint(0, "x", ">", -0.25)                      # constraints are part of the compiled kernels
+        g = c.graph_replay(-0.4)
+        oc = orc.march(eq, step, -0.4, pow_mode=orc.POW_EXACT, want=2, constraints=[("x", ">", -0.25)])
+        assert g.n_tris == oc.n_tris and g.n_tris < want[-0.4].n_tris
+        assert_same_floats(g.vertices()[:, :, :3], oc.soup, "after a constraint change")
+    finally:
+        c.close()
+
+
+def test_graph_async_replays(mc, ctx):
+    """mc_graph_replay_async enqueues without a host round trip; mc_graph_wait reports the last replay.  Replays with
+    different iso values in flight stay ordered (the parameter block is read when the upload node RUNS)."""
+    eq, step = EQ["goursat"], step_of(64)
+    ctx.graph_build(eq, step, iso=-0.4, flags=mc.FLAG_NORMALS | mc.FLAG_NO_TIMING)
+    for _ in range(8):
+        ctx.graph_replay_async(-0.4)
+    ctx.graph_replay_async(-0.25)
+    g = ctx.graph_wait()
+    assert g.ms_total == 0 and g.ms_classify == 0      # FLAG_NO_TIMING: no event nodes in the graph
+    m = ctx.march(eq, step, -0.25, flags=mc.FLAG_NORMALS)
+    assert g.n_tris == m.n_tris and np.array_equal(u32(g.vertices()), u32(m.vertices()))
+
+
 def test_errors(mc, ctx):
     for eq, code in (("sin(x)", mc.MC_ERR_PARSE), ("x+", mc.MC_ERR_EVAL)):
         with pytest.raises(mc.McError) as e:
@@ -319,21 +365,16 @@ EQ_ALL = dict(EQ, **RATIONAL)
                                         ("eq6", 64, 0.0), ("goursat", 96, -0.4), ("ui_default", 40, 0.0),
                                         ("div_pos", 64, 0.0), ("div_lin", 64, 0.0), ("negpow", 64, 0.0),
                                         ("negpow_odd", 64, 0.0), ("div_var", 64, 0.0)])
-def test_interval_row_culling_is_exact(mc, ctx, name, n, iso, monkeypatch):
-    """K1 proves rows / lanes uniform with interval arithmetic (mc_f_iv) and never samples them; a
-    build with the interval walk compiled out (MC_NO_CULL: the sampling walk) must give
-    byte-identical codes and vertices."""
+def test_interval_row_culling_is_exact(mc, ctx, name, n, iso):
+    """K1 proves rows / lanes uniform with interval arithmetic (mc_f_iv) and never samples them; the kernels
+    compiled with the interval walk left out (MC_FLAG_NO_CULL: the sampling walk) must give byte-identical codes
+    and vertices."""
     EQ = EQ_ALL
     a = ctx.march(EQ[name], step_of(n), iso)
     ca, va = a.codes(), a.vertices()
-    monkeypatch.setenv("MC_JIT_EXTRA", "#define MC_NO_CULL 1")
-    plain = mc.Context(0)     # a fresh context: compiled kernels are cached per context
-    try:
-        b = plain.march(EQ[name], step_of(n), iso)
-        assert np.array_equal(ca, b.codes())
-        assert np.array_equal(u32(va), u32(b.vertices()))
-    finally:
-        plain.close()
+    b = ctx.march(EQ[name], step_of(n), iso, flags=mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | mc.FLAG_NO_CULL)
+    assert np.array_equal(ca, b.codes())
+    assert np.array_equal(u32(va), u32(b.vertices()))
 
 
 # ---------------------------------------------------------------- constraints (marching.cpp:173-207, :255-280, :476)
@@ -362,6 +403,9 @@ def test_constraints(mc, orc, name, n, cname):
         assert np.array_equal(r.codes(), o.codes), "cube codes differ"
         assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
         assert_same_floats(r.vertices()[:, :, :3], o.soup, "positions")
+        for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED):     # both emit kernels (skipped cells break up the chunks)
+            rf = c.march(eq, step, flags=mc.FLAG_NORMALS | force)
+            assert_same_floats(rf.vertices()[:, :, :3], o.soup, f"positions, emit flag {force}")
         # switched off again: the unconstrained surface (use_constraint, marching.cpp:202-207)
         for i in range(len(cons)):
             c.use_constraint(i, False)
@@ -397,16 +441,19 @@ def test_constraint_errors(mc):
         c.close()
 
 
-def test_record_buffer_grows_on_demand(mc, orc, monkeypatch):
-    """The dense record array starts from a guess; a surface with more active cells overflows it, the sweep's own
-    count tells the host, which grows the buffer and sweeps again (same path a replayed graph takes)."""
-    monkeypatch.setenv("MC_REC_CAP0", "64")
+def test_record_buffer_grows_on_demand(mc, orc):
+    """The dense record array starts from a guess (16 records per row and layer); a surface with more active cells --
+    here ten planes per axis, 28 % of all cells -- overflows it, the sweep's own count tells the host, which grows the
+    buffer and sweeps again (the same path a replayed graph takes)."""
     c = mc.Context(0)
     try:
-        eq, step = EQ["sphere"], step_of(40)
+        roots = [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9]
+        eq = "*".join(f"({v}{'+' if r < 0 else '-'}{abs(r)})" for v in "xyz" for r in roots)
+        step = step_of(96)
         r = c.march(eq, step)
         o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=3)
-        assert r.n_active > 64 and (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+        assert r.n_active > 16 * r.cells_per_axis ** 2 + 4096, "the case no longer overflows the first guess"
+        assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
         assert np.array_equal(r.codes(), o.codes)
         assert_same_floats(r.vertices()[:, :, :3], o.soup, "positions")
         c.graph_build(eq, step, iso=0.5)            # fewer cells at iso 0.5 ...

@@ -1,0 +1,130 @@
+"""GPU (-m gpu): MC_FLAG_INDEXED -- the reference's indexed Poly_Data built on the device (mc_vmark / mc_vwrite /
+mc_vindex, csrc/mc_kernels.hip) against the oracle's replay of the reference's std::set welding
+(oracle/mc_oracle_weld.cpp; marching.cpp:599-654, marching.h:32-55): vertex_list bit for bit in the reference's order of
+first insertion, tri_list index for index; vertex / triangle counts equal the numbers SURVEY.md section 4 recorded from
+the unmodified reference; every indexed position is bit-equal to a soup position of the same sweep; the area-weighted
+normals (normal.h:3-41) within 1e-5 (the device sums with atomics, the reference in triangle order)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import EQ
+from test_weld_model import CASES, REFERENCE_COUNTS
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def step_of(n):
+    return float(f32(2.0) / f32(n))
+
+
+def check_indexed(mc, orc, c, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0), cons=(), z=(0, -1), soup=True):
+    ref = orc.march_indexed(eq, step, iso, scale, pow_mode=orc.POW_EXACT, constraints=cons, z_begin=z[0], z_end=z[1])
+    flags = mc.FLAG_INDEXED | (mc.FLAG_NORMALS if soup else mc.FLAG_NO_EMIT)
+    r = c.march(eq, step, iso, scale, flags, z[0], z[1])
+    assert (r.n_verts, r.n_tris) == (ref.n_verts, ref.n_tris)
+    v, t, n = r.indexed()
+    assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32)), "vertex_list differs"
+    assert np.array_equal(t, ref.tris), "tri_list differs"
+    ok = np.isfinite(ref.normals).all(axis=1)
+    assert np.array_equal(np.isfinite(n).all(axis=1), ok)
+    if ok.any():
+        assert np.abs(n[ok] - ref.normals[ok]).max() <= 1e-5
+    if soup and r.n_tris:
+        # every corner's welded vertex is within the reference's tolerance of the soup vertex it replaces, and the
+        # welded coordinates are bits the soup holds too (first inserted wins)
+        s = r.vertices()[:, :, :3].reshape(-1, 3)
+        assert np.abs(v[t.reshape(-1)] - s).max() < 1e-6
+        assert set(map(bytes, v.view(np.uint8).reshape(-1, 12))) <= set(map(bytes, s.view(np.uint8).reshape(-1, 12)))
+    return r
+
+
+@pytest.mark.parametrize("eq,step,iso,scale,verts,tris", REFERENCE_COUNTS)
+def test_indexed_counts_equal_the_reference(mc, orc, ctx, eq, step, iso, scale, verts, tris):
+    r = check_indexed(mc, orc, ctx, eq, step, iso, (scale,) * 3)
+    assert (r.n_verts, r.n_tris) == (verts, tris)
+
+
+@pytest.mark.parametrize("eq,step,iso,scale,cons,z", CASES)
+def test_indexed_mesh_equals_the_std_set_replay(mc, orc, eq, step, iso, scale, cons, z):
+    c = mc.Context(0)
+    try:
+        for i, (lhs, op, rhs) in enumerate(cons):
+            c.set_constraint(i, lhs, op, rhs)
+        check_indexed(mc, orc, c, eq, step, iso, (scale,) * 3, cons, z)
+    finally:
+        c.close()
+
+
+def test_indexed_without_soup_and_on_wide_grids(mc, orc, ctx):
+    """MC_FLAG_NO_EMIT | MC_FLAG_INDEXED (what the facade asks for); rows wider than one 256-cell segment, a tail
+    plane (257 cells per axis), groups that straddle layers."""
+    check_indexed(mc, orc, ctx, EQ["sphere"], step_of(48), soup=False)
+    check_indexed(mc, orc, ctx, EQ["sphere"], step_of(256), z=(126, 131))
+    check_indexed(mc, orc, ctx, "x^2+y^2-0.5", step_of(300), z=(149, 152))
+    check_indexed(mc, orc, ctx, "x+y", step_of(256), z=(0, 3))
+
+
+def test_indexed_sphere_256_known_answer(mc, ctx):
+    """the unmodified reference welds the 256-grid sphere into 308 574 vertices / 617 180 triangles."""
+    r = ctx.march(EQ["sphere"], step_of(256), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
+    assert (r.n_verts, r.n_tris) == (308574, 617180)
+    v, t, n = r.indexed()
+    assert t.max() == r.n_verts - 1 and np.abs(np.linalg.norm(v, axis=1) - 1).max() < 1e-3
+    assert (np.sum(n * v, axis=1) > 0.99).all()
+
+
+def test_indexed_sphere_1024_properties(mc, ctx):
+    """The headline grid: a closed surface (every edge in exactly two triangles, Euler characteristic 2 up to the six
+    axis points where the reference welds five vertices into one), all indices used, unit normals pointing outwards."""
+    r = ctx.march(EQ["sphere"], step_of(1024), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
+    assert r.n_tris == 9881660 and r.n_verts == r.n_tris // 2 + 2 - 18
+    v, t, n = r.indexed()
+    assert np.array_equal(np.unique(t), np.arange(r.n_verts, dtype=np.uint32))
+    assert np.abs(np.linalg.norm(v, axis=1) - 1).max() < 1e-3
+    ok = np.isfinite(n).all(axis=1)
+    assert ok.sum() >= r.n_verts - 6 and (np.sum(n[ok] * v[ok], axis=1) > 0.99).all()
+    assert r.ms_index > 0
+
+
+def test_indexed_refused_in_seed_mode_and_graphs(mc):
+    c = mc.Context(0)
+    try:
+        c.set_seed(1.0, 0.0, 0.0)
+        c.seed_mode(True)
+        with pytest.raises(mc.McError) as e:
+            c.march(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED)
+        assert e.value.code == mc.MC_ERR_ARG
+        c.seed_mode(False)
+        with pytest.raises(mc.McError) as e:
+            c.graph_build(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED)
+        assert e.value.code == mc.MC_ERR_ARG
+    finally:
+        c.close()
+
+
+OPS = ["+", "-", "*"]
+
+
+def random_equation(rng):
+    terms = []
+    for _ in range(rng.randint(2, 4)):
+        v = rng.choice(["x", "y", "z"])
+        k = rng.choice(["", "^2", "^3"])
+        terms.append(f"{rng.choice(['', '0.5*', '1.5*', '2*'])}{v}{k}")
+    eq = terms[0]
+    for t in terms[1:]:
+        eq += rng.choice(OPS) + t
+    return eq + rng.choice(["-0.25", "-0.5", "+0.1", ""])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_SEEDS", "24"))))
+def test_indexed_random_equations(mc, orc, ctx, seed):
+    rng = random.Random(7000 + seed)
+    eq = random_equation(rng)
+    step = rng.choice([step_of(16), step_of(24), 0.07, 0.11, step_of(32)])
+    scale = rng.choice([(1.0, 1.0, 1.0), (1.1, 1.1, 1.1), (0.7, 1.3, 1.0)])
+    check_indexed(mc, orc, ctx, eq, step, rng.choice([0.0, 0.1, -0.2]), scale)

@@ -124,22 +124,17 @@ def test_sweep_matches_oracle(mc, orc, ext, eq, n, iso, scale):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("eq,n,scale", [(GYROID, 96, 12.566371), ("cos(x)+cos(y)+cos(z)", 80, 9.424778), (GYROID, 64, 1.0)])
-def test_interval_culling_of_trig_is_exact(mc, ext, eq, n, scale, monkeypatch):
-    """mc_sin_iv / mc_cos_iv enclosures cull rows without sampling; compiled out (MC_NO_CULL) the result is identical."""
+def test_interval_culling_of_trig_is_exact(mc, ext, eq, n, scale):
+    """mc_sin_iv / mc_cos_iv enclosures cull rows without sampling; compiled out (MC_FLAG_NO_CULL) the result is identical."""
     step = float(f32(2.0) / f32(n))
-    a_ctx = mc.Context(0)
+    c = mc.Context(0)
     try:
-        a = a_ctx.march(eq, step, 0.0, (scale,) * 3)
+        a = c.march(eq, step, 0.0, (scale,) * 3)
         ca, va = a.codes(), a.vertices()
-    finally:
-        a_ctx.close()
-    monkeypatch.setenv("MC_JIT_EXTRA", "#define MC_NO_CULL 1")
-    b_ctx = mc.Context(0)
-    try:
-        b = b_ctx.march(eq, step, 0.0, (scale,) * 3)
+        b = c.march(eq, step, 0.0, (scale,) * 3, flags=mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | mc.FLAG_NO_CULL)
         assert np.array_equal(ca, b.codes()) and np.array_equal(_u32(va), _u32(b.vertices()))
     finally:
-        b_ctx.close()
+        c.close()
 
 
 @pytest.mark.gpu
