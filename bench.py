@@ -30,19 +30,45 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-TRAFFIC_PROFILE = ROOT / "profiles" / "r01_pmc_traffic_sphere1024.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+EQ3 = "(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2"   # example_files/equation_3.txt (BASELINE config 3)
+GYROID = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)"                                   # BASELINE config 4 (grammar extension E1)
+PROFILE_TAG = "r02"
 
 
-def pmc_traffic(kernel, workload_ok):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None if the
-    workload differs from the profiled one."""
-    if not workload_ok or not TRAFFIC_PROFILE.exists():
+def traffic_profile(workload_key):
+    """profiles/<tag>_pmc_traffic_<workload>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    (tools/profile_round.py), committed; None when this workload has not been profiled."""
+    f = ROOT / "profiles" / f"{PROFILE_TAG}_pmc_traffic_{workload_key}.json"
+    return f if f.exists() else None
+
+
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md); None if this workload has no profile."""
+    f = traffic_profile(workload_key)
+    if f is None:
         return None
     try:
-        return int(json.loads(TRAFFIC_PROFILE.read_text())[kernel]["hbm_bytes_per_launch_fetch_x2"])
+        return int(json.loads(f.read_text())[kernel]["hbm_bytes_per_launch_fetch_x2"])
     except Exception:
         return None
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly: become the launcher -- N fresh rank processes through
+    torch.distributed.run, started BEFORE this process has touched a GPU (importing torch does not); rank 0's JSON line is
+    relayed and the children's exit code returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
 
 
 def cpu_baseline(eq, step, n1, budget_s=15.0):
@@ -145,9 +171,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid-res", type=int, default=1024)
     ap.add_argument("--equation", default="x^2+y^2+z^2-1")
-    ap.add_argument("--workload", choices=["sphere", "gyroid"], default="sphere",
+    ap.add_argument("--workload", choices=["sphere", "gyroid", "torus"], default="sphere",
                     help="sphere: the headline configuration.  gyroid: BASELINE config 4, sin x cos y + sin y cos z + sin z cos x "
-                         "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1)")
+                         "at 4 periods per axis -- needs the sin/cos grammar extension (not a reference input, DESIGN.md E1).  "
+                         "torus: BASELINE config 3, example_files/equation_3.txt at grid_res 512")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--halo-check", action="store_true",
                     help="N > 1, outside the timed region: exchange the boundary sample plane with the Z neighbour (send/recv) and "
@@ -167,6 +194,9 @@ def main():
                          "512^3 Goursat surface, one captured hipGraph replayed per frame with a new iso value")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import mc_amd
 
@@ -174,7 +204,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # BENCH_FORCE_DIST: world_size 1 through the distributed path (test)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # BENCH_BACKEND=gloo + BENCH_SINGLE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box
@@ -186,8 +217,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    elif args.gpus != 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
 
     if args.mode == "isosweep":
@@ -196,7 +225,11 @@ def main():
     scale = (args.scale,) * 3
     if args.workload == "gyroid":
         mc_amd.set_extensions(mc_amd.EXT_TRIG)
-        eq, scale = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)", (12.566371,) * 3
+        eq, scale = GYROID, (12.566371,) * 3
+    if args.workload == "torus":
+        eq = EQ3
+        if args.grid_res == 1024:
+            args.grid_res = 512
     step = float(np.float32(2.0) / np.float32(args.grid_res))
     n1 = mc_amd.cells_per_axis(step)
     zb, ze = mc_amd.shard_layers(n1, world, rank)
@@ -204,17 +237,9 @@ def main():
         zb, ze = mc_amd.shard_layers(n1, args.slab_of, args.slab_of // 2)
     flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
     ctx = mc_amd.Context(local_rank)
-    cdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
-    counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if world > 1 else None
-    # per-step count exchange without a host stall: the rank's count goes through a pinned slot and an async copy,
-    # the all-gather is enqueued asynchronously (stream-ordered behind it) and only the fence waits for it
-    nslots = args.steps + args.warmup + 1
-    mine_host = torch.zeros(nslots, dtype=torch.int64)
-    if cdev == "cuda":
-        mine_host = mine_host.pin_memory()
-    mine_dev = torch.zeros(nslots, dtype=torch.int64, device=cdev) if world > 1 else None
+    cdev = "cuda" if (multi and dist.get_backend() == "nccl") else "cpu"
+    counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if multi else None
     pending = []
-    step_no = [0]
 
     # Count-balanced Z repartition (untimed): equal-height slabs do not cost the same -- an equatorial slab of the
     # sphere has ~1.3x the undecided rows of the average one -- so each rank times its slab, the times are gathered,
@@ -229,31 +254,57 @@ def main():
             bounds = mc_amd.rebalance_layers(bounds, tdev.cpu().tolist())
             zb, ze = bounds[rank], bounds[rank + 1]
 
-    # steady state: the sweep (parameter upload, classify, scan x3, emit, totals download) is captured once as a
-    # hipGraph and replayed per step -- one launch instead of a dozen API calls (~30 us of host time per sweep)
+    # Steady state: the sweep (parameter upload, one memset, classify, scan, emit; the totals reach pinned host memory
+    # through the scan kernel's own store) is captured once as a hipGraph and replayed per step WITHOUT a host round trip:
+    # K replays are enqueued back to back and the counts are read once at the end.  Two captures: a plain one for the
+    # timed region, one with the per-kernel hipEvent nodes for the kernel times the roofline uses.
+    r0 = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)   # sizes every buffer; this rank's counts
     if not args.no_graph:
-        ctx.graph_build(eq, step, 0.0, scale, flags, zb, ze)
+        ctx.graph_build(eq, step, 0.0, scale, flags | mc_amd.FLAG_NO_TIMING, zb, ze)
+
+    # N > 1, the path's one real exchange -- per-rank triangle counts -> global offsets -- without the host in the loop:
+    # the sweep leaves its counts in device memory (mc_result.d_totals); a side stream, ordered behind the sweep, copies
+    # them into this step's slot and feeds the RCCL all-gather; the next sweep is ordered behind that copy (its memset
+    # clears the counts).  Only the fence at the end of the timed region waits for anything.
+    lib_stream = side = totals_dev = slots = None
+    if multi and cdev == "cuda" and not args.no_graph:
+        class _Raw:   # zero-copy view of the library's {n_tris, n_active} words
+            __cuda_array_interface__ = {"shape": (2,), "typestr": "<i8", "data": (int(r0.d_totals), False), "version": 2}
+        totals_dev = torch.as_tensor(_Raw(), device=f"cuda:{local_rank}")
+        lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
+        side = torch.cuda.Stream(device=f"cuda:{local_rank}")
+        slots = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int64, device=cdev)
+    step_no = [0]
 
     def one_step():
-        r = ctx.graph_replay(0.0) if not args.no_graph else ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
-        if world > 1:  # the path's one real exchange: per-rank triangle counts -> global offsets
-            i = step_no[0] % nslots
+        if args.no_graph:
+            r = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+        else:
+            r = None
+            ctx.graph_replay_async(0.0)
+        if multi:
+            i = step_no[0]
             step_no[0] += 1
-            mine_host[i] = r.n_tris
-            if cdev == "cuda":
-                mine_dev[i:i + 1].copy_(mine_host[i:i + 1], non_blocking=True)
-            else:
-                mine_dev[i] = mine_host[i]
-            pending.append(dist.all_gather_into_tensor(counts_dev, mine_dev[i:i + 1], async_op=True))
+            if totals_dev is not None:
+                side.wait_stream(lib_stream)
+                with torch.cuda.stream(side):
+                    slots[i:i + 1].copy_(totals_dev[0:1], non_blocking=True)
+                    pending.append(dist.all_gather_into_tensor(counts_dev, slots[i:i + 1], async_op=True))
+                lib_stream.wait_stream(side)
+            else:   # gloo rehearsal / --no-graph: through the host
+                n_tris = r.n_tris if r is not None else ctx.graph_wait().n_tris
+                pending.append(dist.all_gather_into_tensor(counts_dev, torch.tensor([n_tris], dtype=torch.int64, device=cdev), async_op=True))
         return r
 
     def fence():
+        r = None if args.no_graph else ctx.graph_wait()
         for wk in pending:
             wk.wait()
         pending.clear()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
+        return r
 
     halo = None
     if world > 1 and args.halo_check:
@@ -265,16 +316,25 @@ def main():
         one_step()
     fence()
     t0 = time.perf_counter()
-    kt = np.zeros(4)
     for _ in range(args.steps):
         r = one_step()
-        kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
-    fence()
+    rf = fence()
     elapsed = time.perf_counter() - t0
+    r = rf if rf is not None else r
+
+    # per-kernel GPU times for the roofline: the same K sweeps again, replayed one by one from a capture that carries the
+    # hipEvent nodes (events are read on the host, so these replays are synchronous; right behind the timed region, same
+    # process, same buffers)
+    kt = np.zeros(4)
+    if not args.no_graph:
+        ctx.graph_build(eq, step, 0.0, scale, flags, zb, ze)
+    for _ in range(args.steps):
+        rk = ctx.graph_replay(0.0) if not args.no_graph else ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+        kt += (rk.ms_classify, rk.ms_scan, rk.ms_emit, rk.ms_total)
     kt /= max(args.steps, 1)
 
     stats = torch.tensor([elapsed, float(r.n_cells), float(r.n_tris), *kt], dtype=torch.float64)
-    if world > 1:
+    if multi:
         stats = stats.to(cdev)
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -284,7 +344,7 @@ def main():
         cells, tris = float(sm[1]), float(sm[2])
         kmax = mx[3:].cpu().numpy()
         offsets, total = mc_amd.exclusive_offsets(counts_dev.cpu().tolist())
-        assert total == int(tris)
+        assert total == int(tris), (total, tris)
     else:
         cells, tris = float(r.n_cells), float(r.n_tris)
         kmax = kt
@@ -299,6 +359,12 @@ def main():
         pipe_bytes = 2.0 * c_launch + 72.0 * t_launch
         cls_gbs = cls_bytes / (ms_cls * 1e-3) / 1e9 if ms_cls > 0 else 0.0
         pipe_gbs = pipe_bytes / (ms_tot * 1e-3) / 1e9 if ms_tot > 0 else 0.0
+        emit_kernel = "mc_emit" if rk.emit_shared else "mc_emit_direct"
+        # committed rocprofv3 PMC passes of this very workload (tools/profile_round.py), if there are any
+        wkey = None
+        if world == 1 and not args.no_normals and args.slab_of <= 1:
+            wkey = {("x^2+y^2+z^2-1", 1024): "sphere1024", (EQ3, 512): "torus512", (GYROID, 1024): "gyroid1024"}.get((eq, args.grid_res))
+        t_cls, t_emit = pmc_traffic("mc_classify", wkey), pmc_traffic(emit_kernel, wkey)
         out = {
             "metric": "Mvoxels/s", "value": round(cells / (elapsed / args.steps) / 1e6, 2), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -307,28 +373,34 @@ def main():
                                    f"({n1}^3 cells), iso 0, scale {scale[0]:g}, normals {'off' if args.no_normals else 'on'}",
                        "cells": int(cells), "triangles": int(tris),
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
-                       "launch": "kernel by kernel" if args.no_graph else "hipGraph replay",
+                       "launch": "kernel by kernel" if args.no_graph else "hipGraph replays enqueued back to back, counts read once",
+                       "count_exchange": (None if not multi else "rccl all_gather_into_tensor, device-side counts" if totals_dev is not None
+                                          else "all_gather_into_tensor through the host"),
                        "z_bounds": bounds if world > 1 else None},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
-                          "gpu_total": round(ms_tot, 4)},
+                          "gpu_total": round(ms_tot, 4), "emit_kernel": emit_kernel,
+                          "source": f"HIP events of {args.steps} synchronous replays right behind the timed region"},
             "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("mc_classify", world == 1 and args.grid_res == 1024 and
-                                                eq == "x^2+y^2+z^2-1" and not args.no_normals),
-                         "traffic_source": "profiles/r01_pmc_traffic_sphere1024.json (rocprofv3 --pmc, per launch)",
+                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4), "traffic": t_cls,
+                         "traffic_source": (f"profiles/{PROFILE_TAG}_pmc_traffic_{wkey}.json (rocprofv3 --pmc, separate passes, per launch)"
+                                            if t_cls is not None else None),
                          "algorithmic_bytes_per_launch": int(cls_bytes)},
-            # mc_emit by what it must write (72 B per triangle); SURVEY 8d also books 1 B/cell of code reads to it, which
-            # the record design never performs -- that byte only appears in the pipeline figure below
-            "emit_roofline": {"bound": "hbm", "kernel": "mc_emit", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            # the emit kernel by what it must write (72 B per triangle); SURVEY 8d also books 1 B/cell of code reads to it,
+            # which the record design never performs -- that byte only appears in the pipeline figure below
+            "emit_roofline": {"bound": "hbm", "kernel": emit_kernel, "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": int(72.0 * t_launch),
                               "achieved": round(72.0 * t_launch / (ms_emit * 1e-3) / 1e9, 1) if ms_emit > 0 else 0.0,
                               "frac": round(72.0 * t_launch / (ms_emit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_emit > 0 else 0.0,
-                              "traffic": pmc_traffic("mc_emit", world == 1 and args.grid_res == 1024 and
-                                                     eq == "x^2+y^2+z^2-1" and not args.no_normals)},
+                              "traffic": t_emit},
+            # the whole chain two ways: against SURVEY 8d's algorithmic bytes (which credit 1 B/cell of code READS this design
+            # never performs), and against the bytes the counters actually see
             "pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(pipe_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(pipe_bytes),
-                         "formula": "2*C + 72*T (SURVEY 8d)"},
+                         "formula": "2*C + 72*T (SURVEY 8d)",
+                         "counter_bytes_per_launch": (t_cls + t_emit) if (t_cls is not None and t_emit is not None) else None,
+                         "frac_by_counter_bytes": (round((t_cls + t_emit) / (ms_tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                   if (t_cls is not None and t_emit is not None and ms_tot > 0) else None)},
         }
         if halo is not None:
             out["halo"] = halo
@@ -336,7 +408,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(eq, step, n1)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -103,6 +103,8 @@ typedef struct mc_result {
     float ms_index;         /* GPU time of the indexed-mesh kernels (hipEvent, ms)                   */
     const uint64_t *d_totals; /* device: {n_tris, n_active} of the sweep, valid in stream order -- lets */
                             /* a multi-GPU host exchange the counts (RCCL) without a host round trip  */
+    int32_t emit_shared;    /* which emit kernel ran: 1 = mc_emit (vertices shared inside a chunk of   */
+                            /* cells, the choice for expensive f), 0 = mc_emit_direct                  */
 } mc_result;
 
 /* -- library ------------------------------------------------------------- */

@@ -45,7 +45,7 @@ class McResult(C.Structure):
                 ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
                 ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p),
                 ("n_verts", C.c_uint64), ("d_vertex_list", C.c_void_p), ("d_tri_list", C.c_void_p), ("d_vertex_normals", C.c_void_p),
-                ("ms_index", C.c_float), ("d_totals", C.c_void_p)]
+                ("ms_index", C.c_float), ("d_totals", C.c_void_p), ("emit_shared", C.c_int32)]
 
 
 class McError(RuntimeError):

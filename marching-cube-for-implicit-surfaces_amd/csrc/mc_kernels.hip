@@ -1373,34 +1373,32 @@ struct McVert {
     float x, y, z;
 };
 
-// position of triangle-vertex `slot` (0..14) of table row `row` in cell (ix,iy,iz):
-// marching.cpp:557-583 (edge interpolation from corner v1 to corner v2 of the edge table) with
-// Marching::interp (:437-446) applied to x, y and z.  The reference evaluates the quotient
-// (iso - v_s)/(v_e - v_s) once per axis with identical operands; it is computed once here.
-// qn: the same intersection seen from the lattice edge's LOWER end -- for the edges the table walks upwards the point
-// itself, for edges 2, 3, 6, 7 it can differ in the last bit -- which is where DESIGN.md N1 takes the normal.
-__device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_axis, const u64* s_row, const u8* s_edge,
-                                            int row, int slot, int ix, int iy, int iz, McVert& qn) {
-    const int edge = (int)((s_row[row] >> (4 * slot)) & 0xF);
-    const int ec = s_edge[edge];
-    const int v1 = ec & 0xF, v2 = ec >> 4;
-    const float xs = s_axis[ix + cx_bit(v1)], xe = s_axis[ix + cx_bit(v2)];
-    const float ys = s_axis[iy + cy_bit(v1)], ye = s_axis[iy + cy_bit(v2)];
-    const float zs = s_axis[iz + cz_bit(v1)], ze = s_axis[iz + cz_bit(v2)];
-    const float vs = mc_F(p, xs, ys, zs);
-    const float ve = mc_F(p, xe, ye, ze);
-    const float t = (p.iso - vs) / (ve - vs);
-    const float dx = xe - xs, dy = ye - ys, dz = ze - zs;
-    const float vx = t * dx, vy = t * dy, vz = t * dz;
+// position of triangle-vertex `slot` (0..14) of table row `row` in cell (ix,iy,iz): marching.cpp:557-583 (edge
+// interpolation from corner v1 to corner v2 of the edge table) with Marching::interp (:437-446).  The reference calls
+// interp for x, y and z; on the two axes the edge does not run along it returns x_s + t*0 = the lattice coordinate, so
+// only the edge's own axis is interpolated here -- from its lower end (p_up) and from its upper end (p_down): the
+// table walks edges 2, 3, 6, 7 downwards and interp is not symmetric, the soup carries the bits of the table's direction.
+// qn: the point with p_up on the axis, which is where DESIGN.md N1 takes the normal (one normal per lattice edge).
+__device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_axis, const u64* s_row, int row, int slot, int ix,
+                                            int iy, int iz, McVert& qn) {
+    const int e = (int)((s_row[row] >> (4 * slot)) & 0xF);
+    const int bx = ix + (int)((MC_EDGE_OX >> e) & 1u), by = iy + (int)((MC_EDGE_OY >> e) & 1u), bz = iz + (int)((MC_EDGE_OZ >> e) & 1u);
+    const int ax = edge_axis(e);
+    const float x0 = s_axis[bx], y0 = s_axis[by], z0 = s_axis[bz];
+    const float c0 = ax == 0 ? x0 : ax == 1 ? y0 : z0;                // the edge's lower end on its axis
+    const float c1 = s_axis[(ax == 0 ? bx : ax == 1 ? by : bz) + 1];  // ... its upper end
+    // the same mc_F, the same operands as the classification of the two corners (marching.cpp:475-479)
+    const float v0 = mc_F(p, x0, y0, z0);
+    const float v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
+    const float pu = mc_interp(p.iso, c0, c1, v0, v1);
+    const float pa = ((MC_EDGE_DOWN >> e) & 1u) ? mc_interp(p.iso, c1, c0, v1, v0) : pu;
+    qn.x = ax == 0 ? pu : x0;
+    qn.y = ax == 1 ? pu : y0;
+    qn.z = ax == 2 ? pu : z0;
     McVert r;
-    r.x = (__builtin_isinf(vx) || __builtin_isnan(vx)) ? xs + 0.5f * dx : xs + vx;
-    r.y = (__builtin_isinf(vy) || __builtin_isnan(vy)) ? ys + 0.5f * dy : ys + vy;
-    r.z = (__builtin_isinf(vz) || __builtin_isnan(vz)) ? zs + 0.5f * dz : zs + vz;
-    qn = r;
-    if ((MC_EDGE_DOWN >> edge) & 1u) {  // an x or y edge walked from its upper to its lower end
-        if (edge & 1) qn.y = mc_interp(p.iso, ye, ys, ve, vs);
-        else qn.x = mc_interp(p.iso, xe, xs, ve, vs);
-    }
+    r.x = ax == 0 ? pa : x0;
+    r.y = ax == 1 ? pa : y0;
+    r.z = ax == 2 ? pa : z0;
     return r;
 }
 
@@ -1417,7 +1415,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                      float* __restrict__ verts) {
     __shared__ u64 s_row[256];
-    __shared__ u8 s_edge[16];
     __shared__ u32 s_list[MC_WPB_E][MC_LIST_CAP];
     __shared__ u32 s_seg[MC_WPB_E][64];
     __shared__ u32 s_act[MC_WPB_E][66];
@@ -1456,7 +1453,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
         for (int k = 0; k < NV; ++k) t[k] = gaxis[min((int)threadIdx.x + NT * k, 511)];
 #pragma unroll
         for (int k = 0; k < NR; ++k) trow[k] = c_tri_row[((int)threadIdx.x + NT * k) & 255];
-        const u8 tedge = c_edge_corner[threadIdx.x < 12 ? threadIdx.x : 0];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int i = (int)threadIdx.x + NT * k;
@@ -1465,7 +1461,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
 #pragma unroll
         for (int k = 0; k < NR; ++k)
             if ((int)threadIdx.x + NT * k < 256) s_row[(int)threadIdx.x + NT * k] = trow[k];
-        if (threadIdx.x < 12) s_edge[threadIdx.x] = tedge;
     }
     // rec_overflow: mc_classify ran out of record space (the host grows the buffer and sweeps again)
     const bool mine = in_range && g0.y != g1.y && rec_overflow == 0u;  // 64 segments with an active cell
@@ -1509,6 +1504,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u32 nverts = 3u * nlist;
+        const u64 room = p.cap_tris > (u64)listbase ? (p.cap_tris - (u64)listbase) * 72ull : 0ull;  // bytes of the vertex array from `listbase` on
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(verts + (u64)listbase * 18ull, 0, (int)(room < 0x7FFFFFF0ull ? room : 0x7FFFFFF0ull), 0x00020000);
         for (u32 v0 = 0; v0 < nverts; v0 += 64u) {
             const u32 vid = v0 + (u32)lane;
             if (vid < nverts) {
@@ -1523,7 +1520,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
                 const int iy = (int)(sr & 2047u), iz = (int)((sr >> 11) & 2047u);
                 const int ix = (int)(sr >> 22) * MC_SEG + cellx;
                 McVert qn;  // where the normal is taken: the edge's intersection point seen from its LOWER end
-                const McVert q = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + k, ix, iy, iz, qn);
+                const McVert q = mc_vertex(p, s_axis, s_row, row, 3 * t + k, ix, iy, iz, qn);
                 float nx = 0.0f, ny = 0.0f, nz = 0.0f;
                 if (want_normals) {
                     // n = g/|g|, g = central difference of F at that point, h = step/2
@@ -1545,9 +1542,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
                         ny = gy * inv;
                         nz = gz * inv;
                     } else {  // degenerate gradient: the triangle's own normal cross(B-A, C-A)
-                        const McVert a = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 0, ix, iy, iz, qn);
-                        const McVert b = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 1, ix, iy, iz, qn);
-                        const McVert c = mc_vertex(p, s_axis, s_row, s_edge, row, 3 * t + 2, ix, iy, iz, qn);
+                        const McVert a = mc_vertex(p, s_axis, s_row, row, 3 * t + 0, ix, iy, iz, qn);
+                        const McVert b = mc_vertex(p, s_axis, s_row, row, 3 * t + 1, ix, iy, iz, qn);
+                        const McVert c = mc_vertex(p, s_axis, s_row, row, 3 * t + 2, ix, iy, iz, qn);
                         const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
                         const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
                         const float cxn = e1y * e2z - e1z * e2y;
@@ -1562,15 +1559,16 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
                         }
                     }
                 }
-                const u64 gtri = (u64)listbase + tri;
-                if (gtri < p.cap_tris) {
-                    // three 8-byte stores per vertex.  (Staging the iteration's 1536 contiguous bytes
-                    // in LDS and writing 16-byte pieces was measured slower: 0.31 vs 0.29 ms.)
-                    float* o = verts + (gtri * 3ull + (u64)k) * 6ull;
-                    ((float2*)o)[0] = make_float2(q.x, q.y);
-                    ((float2*)o)[1] = make_float2(q.z, nx);
-                    ((float2*)o)[2] = make_float2(ny, nz);
-                }
+                // 24 bytes per vertex through a buffer descriptor over the staged part of the vertex array: scalar base,
+                // 32-bit lane offset, and the range check drops what lies beyond the buffer's capacity
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x4 s0;
+                s0.x = q.x; s0.y = q.y; s0.z = q.z; s0.w = nx;
+                f32x2 s1;
+                s1.x = ny; s1.y = nz;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), vrsrc, vid * 24u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, s1), vrsrc, vid * 24u + 16u, 0, 0);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

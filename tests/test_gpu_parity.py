@@ -291,6 +291,20 @@ def test_sphere_256_known_answer(mc, orc, ctx):
     o = orc.march(EQ["sphere"], step_of(256), pow_mode=orc.POW_EXACT, want=orc.WANT_CODES | orc.WANT_SOUP)
     assert np.array_equal(r.codes(), o.codes)
     assert_same_floats(r.soup(), o.soup, "soup @256")
+    # ... and against the reference's own arithmetic (libm powf for ^): the same codes, positions within the north star's 1e-5
+    ref = orc.march(EQ["sphere"], step_of(256), pow_mode=orc.POW_LIBM, want=orc.WANT_CODES | orc.WANT_SOUP)
+    assert np.array_equal(r.codes(), ref.codes) and ref.n_tris == r.n_tris
+    assert np.abs(r.soup() - ref.soup).max() <= TOL_POS
+
+
+def test_torus_128_against_reference_semantics(mc, orc, ctx):
+    """equation_3 (BASELINE config 3's surface) at a size the CPU oracle sweeps in seconds, against libm-powf semantics
+    (what the reference executes): identical cube codes, positions within 1e-5; SURVEY section 4 count 38 388."""
+    r = ctx.march(EQ["eq3"], step_of(128))
+    ref = orc.march(EQ["eq3"], step_of(128), pow_mode=orc.POW_LIBM, want=orc.WANT_CODES | orc.WANT_SOUP)
+    assert r.n_tris == ref.n_tris == 38388
+    assert np.array_equal(r.codes(), ref.codes)
+    assert np.abs(r.soup() - ref.soup).max() <= TOL_POS
 
 
 def test_sphere_128_reference_count(mc, ctx):

@@ -6,6 +6,7 @@ the unmodified reference; every indexed position is bit-equal to a soup position
 normals (normal.h:3-41) within 1e-5 (the device sums with atomics, the reference in triangle order)."""
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -21,18 +22,33 @@ def step_of(n):
     return float(f32(2.0) / f32(n))
 
 
-def check_indexed(mc, orc, c, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0), cons=(), z=(0, -1), soup=True):
+def check_indexed(mc, orc, c, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0), cons=(), z=(0, -1), soup=True, exact=True):
+    """exact=False: the case is known to hold points closer than the reference's 1e-6 tolerance that are NOT bit-identical.
+    The reference's comparator is then not an ordering, and whether its std::set finds the earlier point depends on the
+    shape of its red-black tree at that moment (libstdc++ and MSVC may even disagree); the device merges every such
+    group (tests/weld_model.py states the rule).  Such a case is compared with the rule itself, and with the std::set
+    replay only for what cannot depend on the tree: the triangles, and that the replay never merges MORE."""
     ref = orc.march_indexed(eq, step, iso, scale, pow_mode=orc.POW_EXACT, constraints=cons, z_begin=z[0], z_end=z[1])
     flags = mc.FLAG_INDEXED | (mc.FLAG_NORMALS if soup else mc.FLAG_NO_EMIT)
     r = c.march(eq, step, iso, scale, flags, z[0], z[1])
-    assert (r.n_verts, r.n_tris) == (ref.n_verts, ref.n_tris)
     v, t, n = r.indexed()
-    assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32)), "vertex_list differs"
-    assert np.array_equal(t, ref.tris), "tri_list differs"
-    ok = np.isfinite(ref.normals).all(axis=1)
-    assert np.array_equal(np.isfinite(n).all(axis=1), ok)
-    if ok.any():
-        assert np.abs(n[ok] - ref.normals[ok]).max() <= 1e-5
+    if exact or r.n_verts == ref.n_verts:
+        assert (r.n_verts, r.n_tris) == (ref.n_verts, ref.n_tris)
+        assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32)), "vertex_list differs"
+        assert np.array_equal(t, ref.tris), "tri_list differs"
+        ok = np.isfinite(ref.normals).all(axis=1)
+        assert np.array_equal(np.isfinite(n).all(axis=1), ok)
+        if ok.any():
+            assert np.abs(n[ok] - ref.normals[ok]).max() <= 1e-5
+    else:
+        import weld_model as wm
+        sw = wm.Sweep(eq, step, iso, scale, constraints=cons, z_begin=z[0], z_end=z[1])
+        mv, mt, _ = sw.weld_by_keys()
+        assert r.n_tris == ref.n_tris and 0 < ref.n_verts - r.n_verts <= max(4, ref.n_verts // 200)
+        assert v.shape == mv.shape and np.array_equal(v.view(np.uint32), mv.view(np.uint32)), "vertex_list differs from the rule"
+        assert np.array_equal(t, mt), "tri_list differs from the rule"
+        # the same triangles as the replay, corner for corner, within the reference's own tolerance
+        assert np.abs(v[t.reshape(-1)] - ref.vertices[ref.tris.reshape(-1)]).max() < 1e-6
     if soup and r.n_tris:
         # every corner's welded vertex is within the reference's tolerance of the soup vertex it replaces, and the
         # welded coordinates are bits the soup holds too (first inserted wins)
@@ -64,7 +80,9 @@ def test_indexed_without_soup_and_on_wide_grids(mc, orc, ctx):
     plane (257 cells per axis), groups that straddle layers."""
     check_indexed(mc, orc, ctx, EQ["sphere"], step_of(48), soup=False)
     check_indexed(mc, orc, ctx, EQ["sphere"], step_of(256), z=(126, 131))
-    check_indexed(mc, orc, ctx, "x^2+y^2-0.5", step_of(300), z=(149, 152))
+    # lattice points within 1e-8 of this cylinder that are not exact hits: four groups of near-coincident points the
+    # reference's tree happens to keep apart (see check_indexed)
+    check_indexed(mc, orc, ctx, "x^2+y^2-0.5", step_of(300), z=(149, 152), exact=False)
     check_indexed(mc, orc, ctx, "x+y", step_of(256), z=(0, 3))
 
 
@@ -127,4 +145,4 @@ def test_indexed_random_equations(mc, orc, ctx, seed):
     eq = random_equation(rng)
     step = rng.choice([step_of(16), step_of(24), 0.07, 0.11, step_of(32)])
     scale = rng.choice([(1.0, 1.0, 1.0), (1.1, 1.1, 1.1), (0.7, 1.3, 1.0)])
-    check_indexed(mc, orc, ctx, eq, step, rng.choice([0.0, 0.1, -0.2]), scale)
+    check_indexed(mc, orc, ctx, eq, step, rng.choice([0.0, 0.1, -0.2]), scale, exact=False)

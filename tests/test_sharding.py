@@ -62,12 +62,36 @@ def test_two_rank_gloo_sharded_sweep(tmp_path):
     assert "SHARD_OK" in r.stdout
 
 
+def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N`, started plainly (the way the driver starts it), must become the launcher: N rank
+    processes through torch.distributed.run with the same arguments, before this process touches a GPU.  Checked on CPU by
+    putting a stand-in `torch.distributed.run` in front of the real one that records how it was called."""
+    fake = tmp_path / "torch" / "distributed"
+    fake.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("import os, sys\nopen(os.environ['FAKE_TORCH_LOG'], 'a').write(sys.argv[0] + '\\n')\n")
+    (fake / "__init__.py").write_text("")
+    (fake / "run.py").write_text("import json, os, sys\nprint('SPAWNED ' + json.dumps(sys.argv[1:]))\nsys.exit(7)\n")
+    log = tmp_path / "imports.log"
+    env = dict(os.environ, PYTHONPATH=str(tmp_path), FAKE_TORCH_LOG=str(log))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"], capture_output=True,
+                       text=True, env=env, timeout=120)
+    assert r.returncode == 7, r.stdout + r.stderr            # the children's exit code is the launcher's
+    assert str(ROOT / "bench.py") not in log.read_text().splitlines()   # the launcher itself never imported torch
+    line = [l for l in r.stdout.splitlines() if l.startswith("SPAWNED ")][0]
+    argv = json.loads(line[len("SPAWNED "):])
+    assert "--nproc-per-node=4" in argv and "--nnodes=1" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    i = argv.index(str(ROOT / "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N>1 path (slabs, count all-gather, max-over-ranks timing) with 2 ranks sharing GPU 0."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29534", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+    """bench.py's N>1 path (slabs, count all-gather, max-over-ranks timing) with 2 ranks sharing GPU 0, started the way
+    the driver starts it: plainly, `python bench.py --gpus 2` (bench.py spawns its ranks itself)."""
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
                         "1", "--grid-res", "256", "--halo-check"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -78,6 +102,19 @@ def test_bench_two_ranks_on_one_gpu():
     assert b[0] == 0 and b[-1] == 257 and 0 < b[1] < 257
     # the halo plane a sampled-field design would exchange equals the plane each rank recomputes
     assert d["halo"]["recomputed_plane_identical_to_exchanged"] is True
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    """The `nccl` (= RCCL) branch of bench.py on the one GPU there is: world_size 1 forced through the distributed path --
+    init_process_group with device_id, the stream-ordered copy of the device-side counts, the CUDA all_gather_into_tensor,
+    barrier and the max / sum reductions all execute."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--grid-res", "256",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["triangles"] == 617180 and d["config"]["count_exchange"] == "rccl all_gather_into_tensor, device-side counts"
 
 
 def test_rebalance_layers_equalises_a_known_cost_profile():
