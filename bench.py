@@ -45,7 +45,7 @@ def traffic_profile(workload_key):
 def pmc_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md); None if this workload has no profile."""
-    f = traffic_profile(workload_key)
+    f = traffic_profile(workload_key) if workload_key else None
     if f is None:
         return None
     try:
@@ -147,20 +147,34 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tris = 0
-    gpu_ms = 0.0
+    kt = np.zeros(4)
     for iso in isos:
         r = ctx.graph_replay(float(iso))
         tris += r.n_tris
-        gpu_ms += r.ms_total
+        kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kt /= frames
     n1 = mc_amd.cells_per_axis(step)
+    cells = float(n1) ** 3
+    tpf = tris / frames
     print(json.dumps({"metric": "Mtris/s", "value": round(tris / dt / 1e6, 2), "unit": "Mtris/s", "n_gpus": 1, "steps": frames,
                       "warmup": args.warmup, "ms_per_step": round(dt / frames * 1e3, 4), "higher_is_better": True,
                       "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": f"iso sweep -0.7..-0.1 on {eq}, grid_res {n} ({n1}^3 cells), hipGraph replay per frame",
+                      "config": {"workload": f"iso sweep -0.7..-0.1 on {eq}, grid_res {n} ({n1}^3 cells), one hipGraph replay per frame "
+                                             "(each frame's triangle count is read back: the host round trip is inside the time)",
                                  "frames": frames, "triangles_total": int(tris)},
-                      "mvoxels_per_s": round(n1 ** 3 * frames / dt / 1e6, 1), "gpu_ms_per_frame": round(gpu_ms / frames, 4)}), flush=True)
+                      "mvoxels_per_s": round(n1 ** 3 * frames / dt / 1e6, 1),
+                      "kernel_ms": {"classify": round(kt[0], 4), "scan": round(kt[1], 4), "emit": round(kt[2], 4), "gpu_total": round(kt[3], 4),
+                                    "emit_kernel": "mc_emit" if r.emit_shared else "mc_emit_direct"},
+                      "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cells / (kt[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(cells / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "traffic": pmc_traffic("mc_classify", "goursat512" if n == 512 else None),
+                                   "algorithmic_bytes_per_launch": int(cells)},
+                      "pipeline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "formula": "2*C + 72*T (SURVEY 8d), mean frame",
+                                   "algorithmic_bytes_per_launch": int(2 * cells + 72 * tpf),
+                                   "achieved": round((2 * cells + 72 * tpf) / (kt[3] * 1e-3) / 1e9, 1),
+                                   "frac": round((2 * cells + 72 * tpf) / (kt[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}), flush=True)
     ctx.close()
 
 

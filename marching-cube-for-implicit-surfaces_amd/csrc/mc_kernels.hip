@@ -143,9 +143,11 @@ struct McParams {
     int tail_cells;     // 0, or 1..4: width of the last chunk when it is handled by tail tiles
     int nchunk_main;    // chunks swept by the 256-wide tiles (nchunk, or nchunk-1 with a tail plane)
     int ntile_t;        // tail tiles per layer: ceil(n1/64), one row per lane
-    u32* rec_cursor;    // record allocator, zeroed before every sweep: word 0 = "a region overflowed", then
+    u32* rec_cursor;    // record allocator, clean at the start of every sweep: word 0 = "a region overflowed", then
                         // MC_NCUR bump cursors 128 bytes apart (word 32*(1+k)), one per region of recs
     u64 cap_recs;       // capacity of the record buffer in records (MC_NCUR equal regions)
+    const u32* overflow;  // the overflow word for the kernels BEHIND the scan (the scan moves it into the sweep's totals and
+                          // clears the allocator for the next sweep)
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
@@ -1439,7 +1441,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     const uint2 g0 = grpoff[group], g1 = grpoff[group + 1u];
     const uint2 cb = seg < p.nseg ? segcb[seg] : make_uint2(0u, 0u);  // {triangles | active << 16, first record}
     const u32 cnt = cb.x;
-    const u32 rec_overflow = p.rec_cursor[0];
+    const u32 rec_overflow = p.overflow[0];
     {
         // issue every table load before the first wait: a copy loop would pay one full memory
         // latency per iteration (the compiler waits for each load before its LDS store)
@@ -1791,7 +1793,7 @@ __device__ __forceinline__ bool mc_group_record(const McGroup& g, const u32* __r
     const McParams p = *P;                                                  \
     const u32 ngroups = (p.nseg + 63u) / 64u;                               \
     const u32 group = blockIdx.x * (u32)MC_WPB_I + (u32)w;                  \
-    if (group >= ngroups || p.rec_cursor[0] != 0u) return;                  \
+    if (group >= ngroups || p.overflow[0] != 0u) return;                    \
     McGroup g;                                                              \
     g.segrec = s_seg[w];                                                    \
     g.actoff = s_act[w];                                                    \

@@ -30,20 +30,72 @@ typedef unsigned char u8;
 // scans its tile.  A status entry is two 8-byte words {state << 62 | triangles, state << 62 | active cells}, each
 // written by one agent-scope store (the value travels with its tag: no fence, MI355X_MICROARCH.md "granule"); a reader
 // accepts a pair only when both words carry the same non-zero state (the words are written in order, first to second,
-// and read in the same order, so a torn pair shows two different states).  `status`, `ticket` and `totals` are zeroed
-// by the host's memset node before every sweep.  Spins are bounded: a workgroup that gives up raises totals[3] (the
+// and read in the same order, so a torn pair shows two different states).  `status` and `ticket` are zero when the kernel
+// starts (the host clears the control block once; every sweep leaves it clean, see below).  Spins are bounded: a workgroup that gives up raises totals[3] (the
 // host reads totals[3] from the device copy only when the counts look wrong -- it cannot happen while every workgroup
 // with a lower ticket is running, which the ticket order guarantees).
 #define SCAN_AGG 1ull
 #define SCAN_INC 2ull
 #define SCAN_SPIN_MAX (1u << 24)
-extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(const u64* __restrict__ grpsum, u32 n, uint2* __restrict__ grpoff,
+//
+// The kernel also leaves the control block CLEAN for the next sweep, so that no memset node is needed between sweeps (two
+// fill kernels of ~4.5 us each per sweep, a tenth of a slab's sweep on 8 GPUs): every group sum is zeroed right after
+// it has been read; mc_classify's record cursors are zeroed by slices; its overflow word is moved into totals[2] (where
+// the kernels behind the scan read it) and cleared; and the workgroup that finishes LAST -- a second counter tells --
+// clears the status words, the ticket and that counter: by then no workgroup looks at them any more.
+extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(u64* __restrict__ grpsum, u32 n, uint2* __restrict__ grpoff,
                                                               u64* __restrict__ totals, u64* status, u32* ticket,
-                                                              const u32* __restrict__ overflow_word, u64* __restrict__ totals_host) {
+                                                              u32* __restrict__ cursors, u32 cursor_words, u64* __restrict__ totals_host) {
     typedef hipcub::BlockScan<u64, SCAN_BLOCK> Scan;
     __shared__ typename Scan::TempStorage tmp;
     __shared__ u32 s_bid;
     __shared__ u64 s_pre[2];
+    if (gridDim.x == 1u) {
+        // a list of one tile (small grids): no ticket, no status words, no look-back, no second counter
+        u64 carry_t = 0, carry_a = 0;
+        for (u32 i = 1u + threadIdx.x; i < cursor_words; i += SCAN_BLOCK) cursors[i] = 0u;
+        for (u32 t0 = 0; t0 < n; t0 += SCAN_TILE) {
+            const u32 base = t0 + threadIdx.x * SCAN_ITEMS;
+            u64 item[SCAN_ITEMS];
+            u64 sum = 0;
+#pragma unroll
+            for (int i = 0; i < SCAN_ITEMS; ++i) {
+                u64 v = 0;
+                if (base + i < n) {
+                    v = grpsum[base + i];
+                    grpsum[base + i] = 0ull;
+                }
+                item[i] = sum;
+                sum += v;
+            }
+            u64 excl, agg;
+            Scan(tmp).ExclusiveSum(sum, excl, agg);
+            __syncthreads();
+            const u64 bt = carry_t + (excl & 0xFFFFFFFFull), ba = carry_a + (excl >> 32);
+#pragma unroll
+            for (int i = 0; i < SCAN_ITEMS; ++i)
+                if (base + i < n) grpoff[base + i] = make_uint2((u32)(bt + (item[i] & 0xFFFFFFFFull)), (u32)(ba + (item[i] >> 32)));
+            carry_t += agg & 0xFFFFFFFFull;
+            carry_a += agg >> 32;
+        }
+        if (threadIdx.x == 0) {
+            u64 ovf = 0ull;
+            if (cursors) {
+                ovf = (u64)cursors[0];
+                cursors[0] = 0u;
+            }
+            totals[0] = carry_t;
+            totals[1] = carry_a;
+            totals[2] = ovf;
+            grpoff[n] = make_uint2((u32)carry_t, (u32)carry_a);
+            if (totals_host) {
+                totals_host[0] = carry_t;
+                totals_host[1] = carry_a;
+                totals_host[2] = ovf;
+            }
+        }
+        return;
+    }
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     __syncthreads();
     const u32 b = s_bid;
@@ -53,10 +105,15 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(const u
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         u64 v = 0;
-        if (base + i < n) v = grpsum[base + i];
+        if (base + i < n) {
+            v = grpsum[base + i];
+            grpsum[base + i] = 0ull;  // clean for the next sweep's atomic adds
+        }
         item[i] = sum;  // exclusive within the thread
         sum += v;
     }
+    // mc_classify's record cursors (word 0, the overflow word, is handled by the last workgroup below)
+    for (u32 i = 1u + b * SCAN_BLOCK + threadIdx.x; i < cursor_words; i += gridDim.x * SCAN_BLOCK) cursors[i] = 0u;
     u64 excl, agg;
     Scan(tmp).ExclusiveSum(sum, excl, agg);
     const u64 agg_t = agg & 0xFFFFFFFFull, agg_a = agg >> 32;
@@ -124,7 +181,11 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(const u
             if (b == gridDim.x - 1u) {
                 // totals: {triangles, active cells, mc_classify's "a record region overflowed" word, scan gave up};
                 // mirrored into pinned host memory so that the host needs no copy node behind the sweep
-                const u64 ovf = overflow_word ? (u64)overflow_word[0] : 0ull;
+                u64 ovf = 0ull;
+                if (cursors) {
+                    ovf = (u64)cursors[0];
+                    cursors[0] = 0u;
+                }
                 totals[0] = pre_t + agg_t;
                 totals[1] = pre_a + agg_a;
                 totals[2] = ovf;
@@ -143,6 +204,19 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(const u
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i)
         if (base + i < n) grpoff[base + i] = make_uint2((u32)(bt + (item[i] & 0xFFFFFFFFull)), (u32)(ba + (item[i] >> 32)));
+    // the workgroup that finishes last clears the scan's own state (its look-back is over, like everybody else's)
+    __shared__ u32 s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ticket[1], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        for (u32 i = threadIdx.x; i < 2u * gridDim.x; i += SCAN_BLOCK)
+            __hip_atomic_store(&status[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- indexed mesh: CalculateNormal (Source/normal.h:3-41) on the welded mesh.  Per triangle cross(B-A, C-A) in glm's

@@ -29,14 +29,15 @@ env = dict(os.environ, TMPDIR="/tmp")
 if extra:
     env["MC_JIT_EXTRA"] = extra
 cmd = ["rocprofv3", "--pmc", *counters, "-d", outdir, "-o", "run", "--output-format", "csv", "--",
-       sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *bench_args]
+       sys.executable, os.path.join(repo, "bench.py"), *([] if "--steps" in bench_args else ["--steps", "3", "--warmup", "1"]),
+       *([] if "--mode" in bench_args else ["--no-cpu-baseline"]), *bench_args]
 import signal
 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
 try:
-    out, _ = proc.communicate(timeout=150)
+    out, _ = proc.communicate(timeout=300)
 except subprocess.TimeoutExpired:
     os.killpg(proc.pid, signal.SIGKILL)   # the profiler starts the program as a grandchild: kill the whole group
-    print("rocprofv3 timed out (150 s); counters:", counters)
+    print("rocprofv3 timed out (300 s); counters:", counters)
     sys.exit(2)
 class r:  # noqa
     stdout, stderr = out, ""

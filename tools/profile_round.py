@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Collect the round's profile set on the GPU box (run from the repo root):
 
-    python tools/profile_round.py [--tag r01]
+    python tools/profile_round.py [--tag r02] [--workloads sphere1024,torus512,gyroid1024,goursat512]
 
-  1. rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3`  -> <tag>_kernel_stats_sphere1024.csv
-  2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes        -> <tag>_pmc_traffic_sphere1024.json
+Per workload (BASELINE.json configs 2/headline, 3, 4, 5):
+  1. rocprofv3 --kernel-trace --stats of the bench command                 -> <tag>_kernel_stats_<workload>.csv
+  2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes       -> <tag>_pmc_traffic_<workload>.json
      (HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE counts 64-byte requests as 32 on
      gfx950, see MI355X_MICROARCH.md, HBM / rocprofv3 section)
-  3. rocprofv3 --pmc SQ_* instruction counters                                -> <tag>_sq_counters_sphere1024.json
-  4. the default bench.py run (with the CPU baseline)                         -> <tag>_bench_sphere1024.json
-Everything lands in gpurun_out/profile/; copy what should be judged into profiles/."""
+  3. rocprofv3 --pmc SQ_* instruction counters                              -> <tag>_sq_counters_<workload>.json
+  4. the bench line itself (sphere1024: with the CPU baseline)              -> <tag>_bench_<workload>.json
+Everything lands in gpurun_out/profile/ AND in profiles/ (the traffic file first: bench.py quotes it in step 4)."""
 import glob
 import json
 import os
@@ -19,10 +20,19 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r01"
+tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r02"
+wl = (sys.argv[sys.argv.index("--workloads") + 1] if "--workloads" in sys.argv else "sphere1024,torus512,gyroid1024,goursat512").split(",")
 out = os.path.join(ROOT, "gpurun_out", "profile")
+prof = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
+
+BENCH_ARGS = {
+    "sphere1024": [],
+    "torus512": ["--workload", "torus"],
+    "gyroid1024": ["--workload", "gyroid", "--steps", "5", "--warmup", "1"],
+    "goursat512": ["--mode", "isosweep", "--steps", "30", "--warmup", "3"],
+}
 
 
 def run(cmd, timeout, cwd="/tmp"):
@@ -37,42 +47,58 @@ def run(cmd, timeout, cwd="/tmp"):
     return o
 
 
-bench = [sys.executable, os.path.join(ROOT, "bench.py")]
-# 1. kernel trace
-d = os.path.join(out, "stats")
-shutil.rmtree(d, ignore_errors=True)
-run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "run", "--output-format", "csv", "--", *bench, "--steps", "20", "--warmup", "3",
-     "--no-cpu-baseline"], 300)
-for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats_sphere1024.csv"))
-    print(open(f).read(), flush=True)
+def keep(path, name):
+    shutil.copy(path, os.path.join(out, name))
+    shutil.copy(path, os.path.join(prof, name))
 
-# 2. traffic, one counter per pass
-pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    j = os.path.join(out, f"pmc_{c}.json")
-    o = run([sys.executable, os.path.join(ROOT, "tools", "pmc.py"), j, c], 200, cwd=ROOT)
-    print(o, flush=True)
+
+for w in wl:
+    extra = BENCH_ARGS[w]
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), *extra]
+    steps = [] if "--steps" in extra else ["--steps", "20", "--warmup", "3"]
+    nocpu = [] if "--mode" in extra else ["--no-cpu-baseline"]
+    # 1. kernel trace
+    d = os.path.join(out, f"stats_{w}")
+    shutil.rmtree(d, ignore_errors=True)
+    run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "run", "--output-format", "csv", "--", *bench, *steps, *nocpu], 400)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        keep(f, f"{tag}_kernel_stats_{w}.csv")
+        print(open(f).read(), flush=True)
+    # 2. traffic, one counter per pass
+    pm = {}
+    barg = "|".join(extra)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        j = os.path.join(out, f"pmc_{w}_{c}.json")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc.py"), j]
+        if barg:
+            cmd += ["--bench-args", barg]
+        o = run([*cmd, c], 400, cwd=ROOT)
+        print(o, flush=True)
+        if os.path.exists(j):
+            for k, v in json.load(open(j)).items():
+                pm.setdefault(k, {})[c] = v.get(c, 0.0)
+    traffic = {k: {"FETCH_SIZE_KB_avg_per_launch": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB_avg_per_launch": v.get("WRITE_SIZE", 0.0),
+                   "hbm_bytes_per_launch_fetch_x2": int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024),
+                   "hbm_bytes_per_launch_raw": int((v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024)} for k, v in pm.items()}
+    tj = os.path.join(out, f"{tag}_pmc_traffic_{w}.json")
+    json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
+    if "mc_classify" in traffic:
+        shutil.copy(tj, os.path.join(prof, f"{tag}_pmc_traffic_{w}.json"))
+    # 3. instruction counters
+    j = os.path.join(out, f"{tag}_sq_counters_{w}.json")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc.py"), j]
+    if barg:
+        cmd += ["--bench-args", barg]
+    print(run([*cmd, "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES",
+               "SQ_ACTIVE_INST_VALU"], 400, cwd=ROOT), flush=True)
     if os.path.exists(j):
-        for k, v in json.load(open(j)).items():
-            pm.setdefault(k, {})[c] = v.get(c, 0.0)
-traffic = {k: {"FETCH_SIZE_KB_avg_per_launch": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB_avg_per_launch": v.get("WRITE_SIZE", 0.0),
-               "hbm_bytes_per_launch_fetch_x2": int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024),
-               "hbm_bytes_per_launch_raw": int((v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024)} for k, v in pm.items()}
-json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic_sphere1024.json"), "w"), indent=1, sort_keys=True)
-if "mc_classify" in traffic:  # bench.py quotes the committed traffic profile: refresh it before step 4
-    shutil.copy(os.path.join(out, f"{tag}_pmc_traffic_sphere1024.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_sphere1024.json"))
-
-# 3. instruction counters
-j = os.path.join(out, f"{tag}_sq_counters_sphere1024.json")
-print(run([sys.executable, os.path.join(ROOT, "tools", "pmc.py"), j, "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR",
-           "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"], 200, cwd=ROOT), flush=True)
-
-# 4. the bench line
-o = run([*bench], 400, cwd=ROOT)
-line = [l for l in (o or "").splitlines() if l.startswith("{")]
-if line:
-    open(os.path.join(out, f"{tag}_bench_sphere1024.json"), "w").write(line[-1] + "\n")
-    print(line[-1], flush=True)
-else:
-    print(o)
+        shutil.copy(j, os.path.join(prof, f"{tag}_sq_counters_{w}.json"))
+    # 4. the bench line
+    o = run([*bench, *([] if w == "sphere1024" else nocpu)], 600, cwd=ROOT)
+    line = [l for l in (o or "").splitlines() if l.startswith("{")]
+    if line:
+        for dst in (out, prof):
+            open(os.path.join(dst, f"{tag}_bench_{w}.json"), "w").write(line[-1] + "\n")
+        print(line[-1], flush=True)
+    else:
+        print(o)
