@@ -280,8 +280,8 @@ extern "C" __global__ __launch_bounds__(256) void mc_pack_codes(const u8* __rest
 // =============================================================== seed mode (Marching::seed_mode, marching.cpp:42-137, :310-331)
 // The reference walks breadth-first from the cell that contains the seed to the face neighbours across every face
 // that carries an intersection.  Here the dense sweep has already classified every cell, so the walk runs over the
-// code volume: frontier in, frontier out, one launch per breadth-first level; mc_seed_filter then removes the
-// triangles of unvisited cells from the records before the scan and mc_emit run.  Cell id = (z*n1 + y)*n1 + x.
+// code volume, in one launch (mc_seed_walk); mc_seed_filter then removes the triangles of unvisited cells from the
+// records before the scan and the emit kernel run.  Cell id = (z*n1 + y)*n1 + x.
 #include "../../include/mc_tables_data.h"
 
 __device__ __forceinline__ u32 seed_code(const u8* codes, const u32* tail, u64 pitch, int n1, int main_cells, int x, int y, int z) {
@@ -289,58 +289,131 @@ __device__ __forceinline__ u32 seed_code(const u8* codes, const u32* tail, u64 p
     return x < main_cells ? (u32)codes[row * pitch + (u64)x] : (tail[row] >> (8 * (x - main_cells))) & 0xFFu;
 }
 
-extern "C" __global__ __launch_bounds__(64) void mc_seed_init(u32* __restrict__ visited, u32* __restrict__ frontier, u32* __restrict__ counts,
+// counters of the walk, one per 128-byte line: [0] next queue slot to take, [32] slots handed out to producers, [64] cells
+// fully expanded, [96] a lane gave up (spin bound)
+extern "C" __global__ __launch_bounds__(64) void mc_seed_init(u32* __restrict__ visited, u32* __restrict__ queue, u32* __restrict__ ctr,
                                                     u32 cell) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         visited[cell >> 5] = 1u << (cell & 31u);
-        frontier[0] = cell;
-        counts[0] = 1u;  // level 0 holds the seed's cell
-        counts[1] = 0u;
-        counts[2] = 0u;
+        queue[0] = cell + 1u;  // a queue slot holds cell + 1; 0 = not written yet
+        ctr[0] = 0u;
+        ctr[32] = 1u;
+        ctr[64] = 0u;
+        ctr[96] = 0u;
     }
 }
 
-// One breadth-first level.  The frontier sizes live on the device (counts[level % 3]) so that the host can enqueue many
-// levels without reading anything back: this launch reads counts[lvl % 3], appends to counts[(lvl+1) % 3] and zeroes
-// counts[(lvl+2) % 3] for the launch after it; a fixed grid strides over the frontier, an empty frontier costs a launch.
-// imax: the largest cell index a move may reach (marching.cpp:84-86: x0 + 0.5*step <= 1); the lower bound is index 0
-extern "C" __global__ __launch_bounds__(256) void mc_seed_expand(const u8* __restrict__ codes, const u32* __restrict__ tail, u64 pitch, int n1,
-                                                       int main_cells, int imax, u32* __restrict__ visited,
-                                                       const u32* __restrict__ fin, u32* __restrict__ fout,
-                                                       u32* __restrict__ counts, u32 lvl, u32 cap) {
-    const u32 nin = min(counts[lvl % 3u], cap);
-    u32* __restrict__ nout = counts + (lvl + 1u) % 3u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(lvl + 2u) % 3u] = 0u;
-    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nin; i += gridDim.x * 256u) {
-    const u32 cell = fin[i];
-    const int x = (int)(cell % (u32)n1), y = (int)((cell / (u32)n1) % (u32)n1), z = (int)(cell / ((u32)n1 * (u32)n1));
-    const u32 code = seed_code(codes, tail, pitch, n1, main_cells, x, y, z);
-    if (code == 0u || code == 255u) continue;  // no surface in this cell: its edge list is empty (marching.cpp:508-510)
+// The whole walk in ONE launch: an asynchronous work list instead of one launch per breadth-first level (the order in
+// which the cells of a component are reached does not change the component).  A WAVE takes 64 consecutive queue slots at a
+// time (one atomic add on the head per 64 cells: a single word takes ~90 atomics per microsecond, and 5 M cells were
+// 40 ms of them when every lane dequeued for itself); lane l polls slot base + l until a producer has filled it, expands
+// its cell -- for each face that carries an intersection the neighbour is marked in the visited bitmap with atomicOr and
+// kept if it was new --, the wave's new cells get their slots with ONE atomic add on the tail (wave prefix sum) and are
+// stored as cell + 1 (the value is its own "ready" flag), and the expanded cells are counted with one add.  The walk is
+// over when every appended cell has been expanded (done == tail: no expansion is running, so nothing more can be
+// appended); a lane that finds that, and whose slot lies beyond the tail, is through; a wave leaves when all its lanes are.
+// One loop with a wave-uniform exit and plain if / else inside: a lane that waits must never sit in an inner spin loop of
+// its own -- in lockstep the lane of the same wave that holds the work those lanes wait for would never get its turn.
+// imax: the largest cell index a move may reach (marching.cpp:84-86: x0 + 0.5*step <= 1); the lower bound is index 0.
+#define SEED_SPIN_MAX (1u << 21)  // ~1 s of polling: the whole walk takes milliseconds
+extern "C" __global__ __launch_bounds__(64) void mc_seed_walk(const u8* __restrict__ codes, const u32* __restrict__ tail, u64 pitch, int n1,
+                                                    int main_cells, int imax, u32* __restrict__ visited, u32* queue, u32 qcap, u32* ctr) {
     constexpr unsigned short kfc[6] = MC_FACE_CORNER_INIT;  // marching_lookup.h:25-32
+    const u32 lane = threadIdx.x & 63u;
+    u32 base = 0u;
+    if (lane == 0u) base = atomicAdd(&ctr[0], 64u);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    bool consumed = false;  // this lane's slot of the current block has been expanded
+    bool through = false;   // ... will never be filled: the walk is over
+    u32 spins = 0;
+    for (;;) {
+        const u32 my = base + lane;
+        u32 v = 0u;
+        if (!consumed && !through && my < qcap) v = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool have = v != 0u;
+        u32 fresh[6];
+        u32 nfresh = 0u;
+        if (have) {
+            const u32 cell = v - 1u;
+            const int x = (int)(cell % (u32)n1), y = (int)((cell / (u32)n1) % (u32)n1), z = (int)(cell / ((u32)n1 * (u32)n1));
+            const u32 code = seed_code(codes, tail, pitch, n1, main_cells, x, y, z);
+            const bool surf = code != 0u && code != 255u;  // (a cell without surface has an empty edge list: marching.cpp:508-510)
 #pragma unroll
-    for (int f = 0; f < 6; ++f) {
-        // the face carries an intersection iff its four corners are not all on one side (marching.cpp:62-69)
-        int ones = 0, bx = 0, by = 0, bz = 0;
+            for (int f = 0; f < 6; ++f) {
+                // the face carries an intersection iff its four corners are not all on one side (marching.cpp:62-69)
+                int ones = 0, bx = 0, by = 0, bz = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int v = (kfc[f] >> (4 * k)) & 0xF;
-            ones += (code >> v) & 1u;
-            bx += (0x66 >> v) & 1;
-            by += (0xCC >> v) & 1;
-            bz += v >> 2;
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (kfc[f] >> (4 * k)) & 0xF;
+                    ones += (code >> c) & 1u;
+                    bx += (0x66 >> c) & 1;
+                    by += (0xCC >> c) & 1;
+                    bz += c >> 2;
+                }
+                // marching_lookup.h:43-50 cube_face_normal = the axis on which the face's corners agree
+                const int nx = x + (bx == 4 ? 1 : bx == 0 ? -1 : 0), ny = y + (by == 4 ? 1 : by == 0 ? -1 : 0),
+                          nz = z + (bz == 4 ? 1 : bz == 0 ? -1 : 0);
+                const bool go = surf && ones != 0 && ones != 4 && nx >= 0 && ny >= 0 && nz >= 0 && nx <= imax && ny <= imax && nz <= imax;  // marching.cpp:84-86
+                fresh[f] = 0xFFFFFFFFu;
+                if (go) {
+                    const u32 nc = ((u32)nz * (u32)n1 + (u32)ny) * (u32)n1 + (u32)nx;
+                    const u32 bit = 1u << (nc & 31u);
+                    if (!(atomicOr(&visited[nc >> 5], bit) & bit)) {  // marching.cpp:89-97: queue it unless it is in the set already
+                        fresh[f] = nc;
+                        ++nfresh;
+                    }
+                }
+            }
+            consumed = true;
+            spins = 0;
         }
-        if (ones == 0 || ones == 4) continue;
-        // marching_lookup.h:43-50 cube_face_normal = the axis on which the face's corners agree
-        const int nx = x + (bx == 4 ? 1 : bx == 0 ? -1 : 0), ny = y + (by == 4 ? 1 : by == 0 ? -1 : 0),
-                  nz = z + (bz == 4 ? 1 : bz == 0 ? -1 : 0);
-        if (nx < 0 || ny < 0 || nz < 0 || nx > imax || ny > imax || nz > imax) continue;  // marching.cpp:84-86
-        const u32 nc = ((u32)nz * (u32)n1 + (u32)ny) * (u32)n1 + (u32)nx;
-        const u32 bit = 1u << (nc & 31u);
-        if (!(atomicOr(&visited[nc >> 5], bit) & bit)) {  // marching.cpp:89-97: queue it unless it is in the set already
-            const u32 slot = atomicAdd(nout, 1u);
-            if (slot < cap) fout[slot] = nc;
+        // the wave's new cells: one atomic add on the tail, the slots handed out by a prefix sum
+        u32 incl = nfresh;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, o, 64);
+            if (lane >= (u32)o) incl += t;
         }
-    }
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u64 worked = __ballot(have);
+        if (total) {
+            u32 tb = 0u;
+            if (lane == 0u) tb = atomicAdd(&ctr[32], total);
+            tb = (u32)__builtin_amdgcn_readfirstlane((int)tb);
+            u32 slot = tb + incl - nfresh;
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+                if (have && fresh[f] != 0xFFFFFFFFu) {
+                    if (slot < qcap) __hip_atomic_store(&queue[slot], fresh[f] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++slot;
+                }
+            // (slots beyond the list's end -- cannot happen, it holds every record -- are counted as done right away so
+            // that the walk still ends)
+            const u32 lost = tb + total > qcap ? min(total, tb + total - qcap) : 0u;
+            if (lost && lane == 0u) atomicAdd(&ctr[64], lost);
+        }
+        // after the appends: done == tail then really means "nothing is running"
+        if (worked && lane == 0u) atomicAdd(&ctr[64], (u32)__builtin_popcountll(worked));
+        if (!have && !consumed && !through) {
+            const u32 done = __hip_atomic_load(&ctr[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 tl = __hip_atomic_load(&ctr[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((done == tl && my >= tl) || my >= qcap) through = true;
+            if (++spins > SEED_SPIN_MAX) {
+                ctr[96] = 1u;
+                through = true;
+            }
+        }
+        const u64 open = __ballot(!consumed && !through);
+        if (open == 0ull) {
+            if (__ballot(through)) break;  // the end of the list lies inside (or before) this block: nothing comes after it
+            // every slot of the block has been expanded: the next 64
+            u32 nb = 0u;
+            if (lane == 0u) nb = atomicAdd(&ctr[0], 64u);
+            base = (u32)__builtin_amdgcn_readfirstlane((int)nb);
+            consumed = false;
+        } else if (worked == 0ull) {
+            __builtin_amdgcn_s_sleep(8);
+        }
     }
 }
 
