@@ -24,11 +24,14 @@
 #define MC_TRIG_FN static inline
 #endif
 
-/* which = 0: sin, 1: cos */
+/* which = 0: sin, 1: cos.  Branch-free on purpose: sin(a) and cos(a) of the same a (the gyroid has three such pairs)
+ * then share everything but the quadrant select once both calls are inlined -- an early return for the out-of-range
+ * case put the two reductions into different basic blocks and the compiler kept both. */
 MC_TRIG_FN float mc_trig_eval(float x, int which) {
-    if (!(__builtin_fabsf(x) < 8192.0f)) return __builtin_nanf("");
-    const float k = __builtin_rintf(x * 0.636619772367581343f); /* x * 2/pi, ties to even */
-    float r = x - k * 1.5703125f;
+    const int ok = __builtin_fabsf(x) < 8192.0f; /* false for inf and NaN too */
+    const float xs = ok ? x : 0.0f;
+    const float k = __builtin_rintf(xs * 0.636619772367581343f); /* x * 2/pi, ties to even */
+    float r = xs - k * 1.5703125f;
     r = r - k * 4.837512969970703125e-4f;
     r = r - k * 7.54978995489188216e-8f;
     const float z = r * r;
@@ -37,7 +40,8 @@ MC_TRIG_FN float mc_trig_eval(float x, int which) {
     const int q = ((int)k + which) & 3;
     float v = (q & 1) ? c : s;
     v = (q & 2) ? -v : v;
-    return __builtin_fminf(1.0f, __builtin_fmaxf(-1.0f, v));
+    v = __builtin_fminf(1.0f, __builtin_fmaxf(-1.0f, v));
+    return ok ? v : __builtin_nanf("");
 }
 
 MC_TRIG_FN float mc_sinf(float x) { return mc_trig_eval(x, 0); }

@@ -70,25 +70,28 @@ __device__ __attribute__((noinline)) float mc_pow_general(float a, float b) { re
 // [lo, hi] contains every value mc_sinf COMPUTES on [l, h].  mc_sinf is within 1e-7 (measured 9.3e-8) of
 // the true sine and never exceeds 1 in magnitude (it clamps), and the true sine is monotone between extrema
 // (pi/2 + n*pi): if no extremum can lie in [l, h] the computed endpoint values, widened by 3e-7,
-// bound the range; an extremum that may lie inside (tested in double with a guard band) contributes
-// its +-1.  Arguments are finite and below 8192 here (finite_on_domain, mc_expr.cpp).
-__device__ __forceinline__ void mc_trig_iv(float l, float h, double shift, int which, float& lo, float& hi) {
+// bound the range; an extremum that MAY lie inside contributes its +-1.  "May": the test runs in float (double
+// instructions run at a fraction of the float rate, and this function is what an interval evaluation of a trigonometric
+// f mostly consists of) with a guard band that is wider than the rounding of its three float operations -- a widened
+// test only ever adds a bound of +-1, never drops one: a true extremum n in [l, h] has ka <= n <= kb; with kb > ka both
+// bounds are set, with kb == ka == n the parity is n's.  Arguments are finite and below 8192 here (finite_on_domain).
+__device__ __forceinline__ void mc_trig_iv(float l, float h, float shift, int which, float& lo, float& hi) {
     // extrema of sin at (n + 1/2) pi, of cos at n pi: maxima for even n, minima for odd n
-    const double a = (double)l * 0.31830988618379067154 - shift, b = (double)h * 0.31830988618379067154 - shift;
-    const double eps = 1e-9 * (1.0 + __builtin_fabs(a) + __builtin_fabs(b));
-    const double ka = __builtin_ceil(a - eps), kb = __builtin_floor(b + eps);
+    const float a = l * 0.318309886183790671538f - shift, b = h * 0.318309886183790671538f - shift;
+    const float eps = 1e-6f * (1.0f + __builtin_fabsf(a) + __builtin_fabsf(b));  // |a|, |b| < 2609: their error is below 2e-7 (1 + |a|)
+    const float ka = __builtin_ceilf(a - eps), kb = __builtin_floorf(b + eps);
     const float vl = mc_trig_eval(l, which), vh = mc_trig_eval(h, which);
     lo = __builtin_fminf(vl, vh) - 3e-7f;
     hi = __builtin_fmaxf(vl, vh) + 3e-7f;
     if (kb >= ka) {
         const bool two = kb > ka;
-        const bool even = __builtin_fmod(ka, 2.0) == 0.0;
+        const bool even = (((int)ka) & 1) == 0;
         if (two || even) hi = 1.0f;
         if (two || !even) lo = -1.0f;
     }
 }
-__device__ __forceinline__ void mc_sin_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.5, 0, lo, hi); }
-__device__ __forceinline__ void mc_cos_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.0, 1, lo, hi); }
+__device__ __forceinline__ void mc_sin_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.5f, 0, lo, hi); }
+__device__ __forceinline__ void mc_cos_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.0f, 1, lo, hi); }
 
 //@@MC_F_BEGIN  (replaced by generated code when JIT-compiled)
 __device__ __forceinline__ float mc_f(float x, float y, float z) {
