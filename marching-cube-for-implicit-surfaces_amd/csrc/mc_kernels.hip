@@ -556,6 +556,25 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
 }
 
 
+// Tile end: the per-segment counts of the tile's rows (lane = row) go into the per-GROUP sums the scan runs over (group =
+// 64 consecutive segments).  Consecutive rows fall into the same group 64 / nchunk times in a row, so the counts are summed
+// per run of equal group inside the wave first -- segmented sum: inclusive scan minus the scan value at the run's head,
+// spread by a max-scan (both fields only grow) -- and only the last lane of a run issues the 64-bit atomic: ~6 atomics
+// per tile instead of up to 63 (1.2 M -> 0.3 M per 1025^3 sweep; each is a 64-byte request at the memory side).
+// c = triangles | active cells << 16 of the lane's segment (0 for lanes beyond the tile), sg = its segment index.
+__device__ __forceinline__ void mc_add_group_sums(u64* __restrict__ grpsum, u32 c, u64 sg, int lane) {
+    if (__ballot(c != 0u) == 0ull) return;  // wave-uniform
+    const u32 key = (u32)(sg >> 6);
+    const u32 v = (c & 0xFFFFu) | ((c >> 16) << 17);  // 64 rows: triangles < 2^17, cells < 2^15
+    const u32 incl = wave_inclusive_scan(v);
+    const u32 excl = incl - v;
+    const u32 kprev = (u32)__shfl_up((int)key, 1, 64), knext = (u32)__shfl_down((int)key, 1, 64);
+    const bool head = lane == 0 || kprev != key, last = lane == 63 || knext != key;
+    const u32 base = wave_inclusive_max(head ? excl : 0u);
+    const u32 run = incl - base;
+    if (last && run) atomicAdd(&grpsum[key], (u64)(run & 0x1FFFFu) | ((u64)(run >> 17) << 32));
+}
+
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
                                                                          uint2* __restrict__ segcb, u32* __restrict__ recs,
                                                                          u64* __restrict__ grpsum) {
@@ -702,14 +721,14 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         if (mixedL) rbase = mc_backend<true>(p, tt, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rmt, mixedL, 0u, codes, recs, tailbuf);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const u64 sgt = tt.seg0 + (u64)lane * p.nchunk;
+        const u32 ct = rvalid ? seg_cnt[lane] : 0u;
         if (rvalid) {
             const u32 own = select_by_mask(mixedL, tailbuf[lane], select_by_mask(laneAll, vm, 0u));
             p.codes_tail[(u64)lz * n1 + y0 + lane] = own;
-            const u64 sg = tt.seg0 + (u64)lane * p.nchunk;
-            const u32 c = seg_cnt[lane];
-            segcb[sg] = make_uint2(c, rbase);
-            if (c) atomicAdd(&grpsum[sg >> 6], (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32));
+            segcb[sgt] = make_uint2(ct, rbase);
         }
+        mc_add_group_sums(grpsum, ct, sgt, lane);
         return;
     }
 
@@ -999,13 +1018,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     if (rowPend) rbase = mc_backend(p, tc, tl, s_lut, marker, seg_cnt, recbuf, rowoff, rm, rowPend, vmask, codes, recs);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < ny) {
-        const u64 sg = tc.seg0 + (u64)lane * p.nchunk;
-        const u32 c = seg_cnt[lane];
-        segcb[sg] = make_uint2(c, rbase);
-        // group sums for the scan (group = 64 consecutive segments): triangles | active cells << 32
-        if (c) atomicAdd(&grpsum[sg >> 6], (u64)(c & 0xFFFFu) | ((u64)(c >> 16) << 32));
-    }
+    const u64 sg = tc.seg0 + (u64)lane * p.nchunk;
+    const u32 c = lane < ny ? seg_cnt[lane] : 0u;
+    if (lane < ny) segcb[sg] = make_uint2(c, rbase);
+    // group sums for the scan (group = 64 consecutive segments): triangles | active cells << 32
+    mc_add_group_sums(grpsum, c, sg, lane);
 }
 
 // =============================================================== K3: emit
