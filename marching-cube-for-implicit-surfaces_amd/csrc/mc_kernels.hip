@@ -1675,8 +1675,9 @@ __device__ __forceinline__ int mc_edge_of(int ax, int d0, int d1) {
 }
 
 // owner of the vertex on edge e of cell (ix, iy, iz): cell (qx, qy, qz) and its edge qe
+// corner: the key is a lattice corner (several lattice edges' vertices are welded there), not the lattice edge
 __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, int ix, int iy, int iz, int e, int& qx, int& qy,
-                                           int& qz, int& qe) {
+                                           int& qz, int& qe, bool& corner) {
     const float* __restrict__ axis = p.axis;
     const int ax = edge_axis(e);
     int b[3] = {ix + (int)((MC_EDGE_OX >> e) & 1u), iy + (int)((MC_EDGE_OY >> e) & 1u), iz + (int)((MC_EDGE_OZ >> e) & 1u)};
@@ -1686,6 +1687,7 @@ __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restri
     const float v0 = mc_F(p, x0, y0, z0);
     const float v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
     const int sn = mc_snap(p.iso, c0, c1, v0, v1);
+    corner = sn != 0;
     if (sn == 0) {
         // lattice-edge key: the first of the (up to) four cells around the edge, in sweep order
         const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
@@ -1834,15 +1836,19 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
         u32 ownm = 0;
         if (valid) {
-            u32 m = crossed_edges((rec >> 8) & 0xFFu);
+            u32 m = crossed_edges((rec >> 8) & 0xFFu), cornm = 0;
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
-                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe);
-                if (qx == ix && qy == iy && qz == iz && qe == e) ownm |= 1u << e;
+                bool corner;
+                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe, corner);
+                if (qx == ix && qy == iy && qz == iz && qe == e) {
+                    ownm |= 1u << e;
+                    if (corner) cornm |= 1u << e;
+                }
             }
-            recown[ridx] = ownm;
+            recown[ridx] = ownm | (cornm << 16);  // bits 0..11: owned edges; 16..27: those of them whose key is a lattice corner
         }
         total += (u32)__builtin_popcount(ownm);
     }
@@ -1862,7 +1868,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vwrite(const McPa
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        const u32 ownm = valid ? recown[ridx] : 0u;
+        const u32 ownm = valid ? recown[ridx] & 0xFFFu : 0u;
         const u32 c = (u32)__builtin_popcount(ownm);
         const u32 incl = wave_inclusive_scan(c);
         u32 vb = carry + incl - c;
@@ -1917,7 +1923,8 @@ __device__ __forceinline__ u32 mc_find_record(const McParams& p, const u32* __re
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                        const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                        const u8* __restrict__ codes, const u32* __restrict__ recown,
-                                                                       const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris) {
+                                                                       const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris,
+                                                                       u32* __restrict__ rectri) {
     __shared__ u32 s_eidx[MC_WPB_I][64 * 13];  // per lane: the vertex index of each of its 12 edges (stride 13: no bank conflicts)
     MC_GROUP_LDS
     u32* eidx = s_eidx[w] + 13 * lane;
@@ -1927,17 +1934,19 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
         if (valid) {
             const u32 code = (rec >> 8) & 0xFFu;
-            const u32 myown = recown[ridx], myvb = recvb[ridx];
+            const u32 myown = recown[ridx] & 0xFFFu, myvb = recvb[ridx];
+            rectri[ridx] = gtri0;  // the record's first triangle, for mc_vnormal
             u32 m = crossed_edges(code);
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
-                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe);
+                bool corner;
+                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe, corner);
                 u32 o = myown, vb = myvb;
                 if (!(qx == ix && qy == iy && qz == iz)) {
                     const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
-                    o = recown[q];
+                    o = recown[q] & 0xFFFu;
                     vb = recvb[q];
                 }
                 eidx[e] = vb + (u32)__builtin_popcount(o & ((1u << qe) - 1u));
@@ -1954,6 +1963,95 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                     o[2] = eidx[(tr >> (12u * t + 8u)) & 0xFull];
                 }
             }
+        }
+    }
+}
+
+// the record of cell (qx, qy, qz), or ~0 when that cell is outside the slab or has none (no surface / skipped)
+__device__ __forceinline__ u32 mc_find_record_opt(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb, int qx, int qy,
+                                                  int qz) {
+    if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.z_begin || qz >= p.z_begin + p.nz) return 0xFFFFFFFFu;
+    const u32 seg = (u32)(((qz - p.z_begin) * p.n1 + qy) * p.nchunk + (qx >> 8));
+    const uint2 cb = segcb[seg];
+    u32 lo = cb.y, n = cb.x >> 16;
+    if (n == 0u) return 0xFFFFFFFFu;
+    const u32 want = (u32)(qx & 255);
+    while (n > 1u) {  // lower bound
+        const u32 half = n >> 1;
+        if ((recs[lo + half - 1u] & 0xFFu) < want) {
+            lo += half;
+            n -= half;
+        } else {
+            n = half;
+        }
+    }
+    return (recs[lo] & 0xFFu) == want ? lo : 0xFFFFFFFFu;
+}
+
+// I4: CalculateNormal (Source/normal.h:3-41) on the welded mesh, as a GATHER: one lane per vertex (= per owned edge of a
+// record) visits the cells that can hold a triangle on that vertex -- the 4 cells around its lattice edge, or, when the
+// vertex is welded to a lattice corner, the 12 cells around the edge's two ends -- in sweep order, their triangles in
+// table order, and adds cross(B-A, C-A) for every corner that IS the vertex: exactly the additions the reference performs
+// on vNormal[i], in the reference's order (its loop runs over the triangles in emission order), so the sums -- and the
+// normalised result, glm's v * (1 / sqrt(dot(v, v))) -- are the reference's bits.  (A scatter with float atomics was
+// 3.1 ms of the 3.7 ms the indexed mesh took at 1025^3: 89 M single-float atomics to scattered addresses run at a
+// seventeenth of the rate contiguous ones do, and their sums depended on arrival order.)
+extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McParams* __restrict__ P, const u32* __restrict__ recs,
+                                                                        const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                                        const u32* __restrict__ recown, const u32* __restrict__ recvb,
+                                                                        const u32* __restrict__ rectri, const u32* __restrict__ tlist,
+                                                                        const float* __restrict__ vlist, float* __restrict__ vnrm, u64 nverts) {
+    MC_GROUP_LDS
+    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+        u32 ridx, rec, gtri0;
+        int ix, iy, iz;
+        const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
+        if (!valid) continue;
+        const u32 ow = recown[ridx];
+        u32 v = recvb[ridx];
+        u32 m = ow & 0xFFFu;
+        while (m) {
+            const int e = __builtin_ctz(m);
+            m &= m - 1u;
+            const bool corner = (ow >> (16 + e)) & 1u;
+            const int ax = edge_axis(e);
+            // lower end of the lattice edge; candidate cells: offsets -1 / 0 on the two other axes, 0 on the edge's axis
+            // (edge key) or -1 / 0 / +1 (corner key: the cells around either end)
+            const int bx = ix + (int)((MC_EDGE_OX >> e) & 1u), by = iy + (int)((MC_EDGE_OY >> e) & 1u), bz = iz + (int)((MC_EDGE_OZ >> e) & 1u);
+            const int a_lo = corner ? -1 : 0, a_hi = corner ? 1 : 0;
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            for (int dz = (ax == 2 ? a_lo : -1); dz <= (ax == 2 ? a_hi : 0); ++dz)
+                for (int dy = (ax == 1 ? a_lo : -1); dy <= (ax == 1 ? a_hi : 0); ++dy)
+                    for (int dx = (ax == 0 ? a_lo : -1); dx <= (ax == 0 ? a_hi : 0); ++dx) {
+                        const u32 q = mc_find_record_opt(p, recs, segcb, bx + dx, by + dy, bz + dz);
+                        if (q == 0xFFFFFFFFu) continue;
+                        const u32 nt = (recs[q] >> 17) & 7u;
+                        const u32 t0 = rectri[q];
+                        for (u32 t = 0; t < nt; ++t) {
+                            const u32* tri = tlist + 3ull * (t0 + t);
+                            const u32 i1 = tri[0], i2 = tri[1], i3 = tri[2];
+                            const int hits = (i1 == v ? 1 : 0) + (i2 == v ? 1 : 0) + (i3 == v ? 1 : 0);
+                            if (!hits || i1 >= nverts || i2 >= nverts || i3 >= nverts) continue;
+                            const float ax_ = vlist[3ull * i1], ay_ = vlist[3ull * i1 + 1], az_ = vlist[3ull * i1 + 2];
+                            const float bax = vlist[3ull * i2] - ax_, bay = vlist[3ull * i2 + 1] - ay_, baz = vlist[3ull * i2 + 2] - az_;
+                            const float cax = vlist[3ull * i3] - ax_, cay = vlist[3ull * i3 + 1] - ay_, caz = vlist[3ull * i3 + 2] - az_;
+                            // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
+                            const float nx = bay * caz - cay * baz, ny = baz * cax - caz * bax, nz = bax * cay - cax * bay;
+                            for (int h = 0; h < hits; ++h) {  // vNormal[i] = normal + vNormal[i], once per corner that is the vertex
+                                sx = nx + sx;
+                                sy = ny + sy;
+                                sz = nz + sz;
+                            }
+                        }
+                    }
+            if ((u64)v < nverts) {
+                const float d = (sx * sx + sy * sy) + sz * sz;
+                const float inv = 1.0f / __builtin_sqrtf(d);  // glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt
+                vnrm[3ull * v] = sx * inv;
+                vnrm[3ull * v + 1] = sy * inv;
+                vnrm[3ull * v + 2] = sz * inv;
+            }
+            ++v;
         }
     }
 }

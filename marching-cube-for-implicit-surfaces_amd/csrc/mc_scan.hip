@@ -219,40 +219,6 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(u64* __
     }
 }
 
-// ---- indexed mesh: CalculateNormal (Source/normal.h:3-41) on the welded mesh.  Per triangle cross(B-A, C-A) in glm's
-// operation order, added to its three vertices; then every vertex normal * (1 / sqrt(dot)).  The reference adds in
-// triangle order, the atomics here in arrival order: same sums up to float rounding (a tolerance quantity; a vertex
-// without triangles, or with a zero sum, comes out NaN exactly as it does there).
-extern "C" __global__ __launch_bounds__(256) void mc_nrm_accum(const float* __restrict__ vlist, const u32* __restrict__ tlist, u64 ntris,
-                                                    u64 nverts, float* __restrict__ nacc) {
-    const u64 t = (u64)blockIdx.x * 256ull + threadIdx.x;
-    if (t >= ntris) return;
-    const u32 i1 = tlist[3 * t], i2 = tlist[3 * t + 1], i3 = tlist[3 * t + 2];
-    if (i1 >= nverts || i2 >= nverts || i3 >= nverts) return;
-    const float ax = vlist[3ull * i1], ay = vlist[3ull * i1 + 1], az = vlist[3ull * i1 + 2];
-    const float bax = vlist[3ull * i2] - ax, bay = vlist[3ull * i2 + 1] - ay, baz = vlist[3ull * i2 + 2] - az;
-    const float cax = vlist[3ull * i3] - ax, cay = vlist[3ull * i3 + 1] - ay, caz = vlist[3ull * i3 + 2] - az;
-    const float nx = bay * caz - cay * baz, ny = baz * cax - caz * bax, nz = bax * cay - cax * bay;
-    const u32 idx[3] = {i1, i2, i3};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        unsafeAtomicAdd(&nacc[3ull * idx[k]], nx);
-        unsafeAtomicAdd(&nacc[3ull * idx[k] + 1], ny);
-        unsafeAtomicAdd(&nacc[3ull * idx[k] + 2], nz);
-    }
-}
-
-extern "C" __global__ __launch_bounds__(256) void mc_nrm_finish(float* __restrict__ nacc, u64 nverts) {
-    const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
-    if (i >= nverts) return;
-    const float x = nacc[3 * i], y = nacc[3 * i + 1], z = nacc[3 * i + 2];
-    const float d = (x * x + y * y) + z * z;
-    const float inv = 1.0f / __builtin_sqrtf(d);
-    nacc[3 * i] = x * inv;
-    nacc[3 * i + 1] = y * inv;
-    nacc[3 * i + 2] = z * inv;
-}
-
 // positions only: verts[T*3][6] -> soup[T*3][3]
 extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __restrict__ verts, float* __restrict__ soup, u64 nverts) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;

@@ -3,7 +3,7 @@ mc_vindex, csrc/mc_kernels.hip) against the oracle's replay of the reference's s
 (oracle/mc_oracle_weld.cpp; marching.cpp:599-654, marching.h:32-55): vertex_list bit for bit in the reference's order of
 first insertion, tri_list index for index; vertex / triangle counts equal the numbers SURVEY.md section 4 recorded from
 the unmodified reference; every indexed position is bit-equal to a soup position of the same sweep; the area-weighted
-normals (normal.h:3-41) within 1e-5 (the device sums with atomics, the reference in triangle order)."""
+normals (normal.h:3-41) bit for bit (the device gathers each vertex's triangles in the reference's order)."""
 import os
 import random
 import sys
@@ -36,10 +36,10 @@ def check_indexed(mc, orc, c, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0), cons=(),
         assert (r.n_verts, r.n_tris) == (ref.n_verts, ref.n_tris)
         assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32)), "vertex_list differs"
         assert np.array_equal(t, ref.tris), "tri_list differs"
-        ok = np.isfinite(ref.normals).all(axis=1)
-        assert np.array_equal(np.isfinite(n).all(axis=1), ok)
-        if ok.any():
-            assert np.abs(n[ok] - ref.normals[ok]).max() <= 1e-5
+        # CalculateNormal: the device adds each vertex's triangle normals in the reference's order -> the same bits
+        # (NaN where the reference's sum is zero)
+        assert np.array_equal(n.view(np.uint32) | (np.isnan(n) * np.uint32(0x7FFFFFFF)),
+                              ref.normals.view(np.uint32) | (np.isnan(ref.normals) * np.uint32(0x7FFFFFFF))), "vertex normals differ"
     else:
         import weld_model as wm
         sw = wm.Sweep(eq, step, iso, scale, constraints=cons, z_begin=z[0], z_end=z[1])
