@@ -268,8 +268,8 @@ def main():
             bounds = mc_amd.rebalance_layers(bounds, tdev.cpu().tolist())
             zb, ze = bounds[rank], bounds[rank + 1]
 
-    # Steady state: the sweep (parameter upload, one memset, classify, scan, emit; the totals reach pinned host memory
-    # through the scan kernel's own store) is captured once as a hipGraph and replayed per step WITHOUT a host round trip:
+    # Steady state: the sweep (classify, scan, emit -- three kernel nodes; the totals reach pinned host memory through the
+    # scan kernel's own store) is captured once as a hipGraph and replayed per step WITHOUT a host round trip:
     # K replays are enqueued back to back and the counts are read once at the end.  Two captures: a plain one for the
     # timed region, one with the per-kernel hipEvent nodes for the kernel times the roofline uses.
     r0 = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)   # sizes every buffer; this rank's counts
@@ -278,7 +278,7 @@ def main():
 
     # N > 1, the path's one real exchange -- per-rank triangle counts -> global offsets -- without the host in the loop:
     # the sweep leaves its counts in device memory (mc_result.d_totals); a side stream, ordered behind the sweep, copies
-    # them into this step's slot and feeds the RCCL all-gather; the next sweep is ordered behind that copy (its memset
+    # them into this step's slot and feeds the RCCL all-gather; the next sweep is ordered behind that copy (its scan
     # clears the counts).  Only the fence at the end of the timed region waits for anything.
     lib_stream = side = totals_dev = slots = None
     if multi and cdev == "cuda" and not args.no_graph:

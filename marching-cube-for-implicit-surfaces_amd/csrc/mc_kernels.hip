@@ -26,7 +26,8 @@
 //                             segment -- 5 GB of address space at 1025^3, touched 12 bytes at a time -- cost
 //                             0.10 ms in mc_classify alone: measured by confining the writes to a window.)
 //   grpsum u64[ngroups]       per GROUP of 64 consecutive segments: triangles | active cells << 32
-//                             (64-bit atomic adds by mc_classify; zeroed before every sweep)
+//                             (64-bit atomic adds by mc_classify, one per run of a tile's rows that share a group;
+//                             left zero by the previous sweep's scan)
 //   grpoff uint2[ngroups+1]   exclusive scan of grpsum: {triangle offset, active-cell offset}
 //   tail   u32[rows]          only when the last chunk is 1..4 cells wide (n1 = 2^k+1): those cells' codes,
 //                             one dword per row, instead of a 128-byte line per row in `codes`
