@@ -125,7 +125,9 @@ int mc_expr_check(const char *equation);
 /* Compile to the evaluation DAG the reference's two-stack walk performs (evaluator.cpp:22-107).
  * Returns MC_OK / MC_ERR_PARSE / MC_ERR_EVAL.  Pure host work, no GPU needed. */
 int mc_expr_validate(const char *equation);
-/* Writes the generated device function (HIP source text of mc_f) into buf; returns its full length.
+/* Writes the generated device code (HIP source text of mc_f, then -- for equations that are finite on the unit-scale
+ * domain -- its interval enclosure mc_f_iv and, when f has expensive sub-expressions of y alone, the staged form
+ * mc_f_iv_y / mc_f_iv_rest the classify walk uses) into buf; returns its full length.
  * Lets a maintainer audit the evaluation order (e.g. x-y-z becomes x-(y-z)). */
 size_t mc_expr_dump(const char *equation, char *buf, size_t cap);
 /* Diagnostic: interpret the compiled DAG on the host for ONE point (same op order and float ops

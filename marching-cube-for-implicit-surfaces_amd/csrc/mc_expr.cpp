@@ -444,11 +444,11 @@ bool finite_on_domain(const Program& p, double radius) {
     return true;
 }
 
-std::string emit_hip_interval(const Program& p, const char* fname) {
-    std::string s;
+namespace {
+// Interval code of ONE node (appended to s): `const float l<i> = ..., h<i> = ...;` from its operands' l / h (variables are
+// xl/xh, yl/yh, zl/zh).  false: the node cannot be bounded (general pow).
+bool iv_node(const Program& p, size_t i, std::string& s) {
     char buf[512];
-    s += std::string("__device__ __forceinline__ void ") + fname + "(float xl, float xh, float yl, float yh, float zl, float zh, float& lo, float& hi) {\n";
-    s += "    (void)xl; (void)xh; (void)yl; (void)yh; (void)zl; (void)zh;\n";
     auto L = [&](int id) -> std::string {
         const Node& n = p.nodes[id];
         if (n.op == NodeOp::VARX) return "xl";
@@ -471,107 +471,199 @@ std::string emit_hip_interval(const Program& p, const char* fname) {
         std::snprintf(buf, sizeof buf, "__uint_as_float(0x%08xu)", u);
         return buf;
     };
-    for (size_t i = 0; i < p.nodes.size(); ++i) {
-        const Node& n = p.nodes[i];
-        const std::string l = L((int)i), h = H((int)i);
-        std::string lo, hi, pre;
-        switch (n.op) {
-        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: continue;
-        case NodeOp::CONST: lo = hi = cst(n.cval); break;
-        case NodeOp::ADD: lo = L(n.a) + " + " + L(n.b); hi = H(n.a) + " + " + H(n.b); break;
-        case NodeOp::SUB: lo = L(n.a) + " - " + H(n.b); hi = H(n.a) + " - " + L(n.b); break;
-        case NodeOp::NEG: lo = "-" + H(n.a); hi = "-" + L(n.a); break;
-        case NodeOp::MUL: {
-            const Node& A = p.nodes[n.a];
-            const Node& B = p.nodes[n.b];
-            if (n.a == n.b) {  // square: |x| in [mn, mx]
+    const Node& n = p.nodes[i];
+    const std::string l = L((int)i), h = H((int)i);
+    std::string lo, hi, pre;
+    switch (n.op) {
+    case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: return true;
+    case NodeOp::CONST: lo = hi = cst(n.cval); break;
+    case NodeOp::ADD: lo = L(n.a) + " + " + L(n.b); hi = H(n.a) + " + " + H(n.b); break;
+    case NodeOp::SUB: lo = L(n.a) + " - " + H(n.b); hi = H(n.a) + " - " + L(n.b); break;
+    case NodeOp::NEG: lo = "-" + H(n.a); hi = "-" + L(n.a); break;
+    case NodeOp::MUL: {
+        const Node& A = p.nodes[n.a];
+        const Node& B = p.nodes[n.b];
+        if (n.a == n.b) {  // square: |x| in [mn, mx]
+            pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
+                  "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
+                  std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
+                  " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
+                  std::to_string(i) + "b);\n";
+            lo = "q" + std::to_string(i) + "n * q" + std::to_string(i) + "n";
+            hi = "q" + std::to_string(i) + "m * q" + std::to_string(i) + "m";
+        } else if (A.op == NodeOp::CONST || B.op == NodeOp::CONST) {
+            const bool a_const = A.op == NodeOp::CONST;
+            const float c = a_const ? A.cval : B.cval;
+            const int v = a_const ? n.b : n.a;
+            // keep the operand order of mc_f (a * b) so both round identically
+            auto prod = [&](const std::string& x) { return a_const ? cst(c) + " * " + x : x + " * " + cst(c); };
+            if (c >= 0.0f) { lo = prod(L(v)); hi = prod(H(v)); }
+            else { lo = prod(H(v)); hi = prod(L(v)); }
+        } else {
+            const std::string t = "p" + std::to_string(i);
+            pre = "    const float " + t + "a = " + L(n.a) + " * " + L(n.b) + ", " + t + "b = " + L(n.a) + " * " + H(n.b) + ", " +
+                  t + "c = " + H(n.a) + " * " + L(n.b) + ", " + t + "d = " + H(n.a) + " * " + H(n.b) + ";\n";
+            lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
+            hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
+        }
+        break;
+    }
+    case NodeOp::DIV: {
+        const Node& B = p.nodes[n.b];
+        if (B.op == NodeOp::CONST && B.cval != 0.0f) {
+            if (B.cval > 0.0f) { lo = L(n.a) + " / " + cst(B.cval); hi = H(n.a) + " / " + cst(B.cval); }
+            else { lo = H(n.a) + " / " + cst(B.cval); hi = L(n.a) + " / " + cst(B.cval); }
+        } else {
+            // finite_on_domain() proved the divisor keeps one sign (and stays away from 0) on the
+            // whole domain, so the quotient is monotone in each operand: extremes at the corners
+            const std::string t = "d" + std::to_string(i);
+            pre = "    const float " + t + "a = " + L(n.a) + " / " + L(n.b) + ", " + t + "b = " + L(n.a) + " / " + H(n.b) + ", " +
+                  t + "c = " + H(n.a) + " / " + L(n.b) + ", " + t + "d = " + H(n.a) + " / " + H(n.b) + ";\n";
+            lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
+            hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
+        }
+        break;
+    }
+    case NodeOp::POWI: {
+        if (n.ipow == 0 || n.ipow == 1) return false;
+        std::snprintf(buf, sizeof buf, "mc_pow_int<%d>", n.ipow);
+        const std::string pw = buf;
+        if (n.ipow < 0) {
+            // base keeps one sign and stays away from 0 (finite_on_domain): x^-n decreases in |x|
+            if ((-n.ipow) % 2 == 0) {
                 pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
-                      "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
-                      std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
-                      " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
-                      std::to_string(i) + "b);\n";
+                      "b = __builtin_fabsf(" + H(n.a) + ");\n";
+                lo = pw + "(__builtin_fmaxf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
+                hi = pw + "(__builtin_fminf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
+            } else {
+                lo = pw + "(" + H(n.a) + ")";
+                hi = pw + "(" + L(n.a) + ")";
+            }
+        } else if (n.ipow % 2 == 0) {
+            pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
+                  "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
+                  std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
+                  " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
+                  std::to_string(i) + "b);\n";
+            if (n.ipow == 2) {
                 lo = "q" + std::to_string(i) + "n * q" + std::to_string(i) + "n";
                 hi = "q" + std::to_string(i) + "m * q" + std::to_string(i) + "m";
-            } else if (A.op == NodeOp::CONST || B.op == NodeOp::CONST) {
-                const bool a_const = A.op == NodeOp::CONST;
-                const float c = a_const ? A.cval : B.cval;
-                const int v = a_const ? n.b : n.a;
-                // keep the operand order of mc_f (a * b) so both round identically
-                auto prod = [&](const std::string& x) { return a_const ? cst(c) + " * " + x : x + " * " + cst(c); };
-                if (c >= 0.0f) { lo = prod(L(v)); hi = prod(H(v)); }
-                else { lo = prod(H(v)); hi = prod(L(v)); }
             } else {
-                const std::string t = "p" + std::to_string(i);
-                pre = "    const float " + t + "a = " + L(n.a) + " * " + L(n.b) + ", " + t + "b = " + L(n.a) + " * " + H(n.b) + ", " +
-                      t + "c = " + H(n.a) + " * " + L(n.b) + ", " + t + "d = " + H(n.a) + " * " + H(n.b) + ";\n";
-                lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
-                hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
+                lo = pw + "(q" + std::to_string(i) + "n)";
+                hi = pw + "(q" + std::to_string(i) + "m)";
             }
-            break;
+        } else {  // odd power: monotone increasing, also as computed (product chain of same-sign factors)
+            lo = pw + "(" + L(n.a) + ")";
+            hi = pw + "(" + H(n.a) + ")";
         }
-        case NodeOp::DIV: {
-            const Node& B = p.nodes[n.b];
-            if (B.op == NodeOp::CONST && B.cval != 0.0f) {
-                if (B.cval > 0.0f) { lo = L(n.a) + " / " + cst(B.cval); hi = H(n.a) + " / " + cst(B.cval); }
-                else { lo = H(n.a) + " / " + cst(B.cval); hi = L(n.a) + " / " + cst(B.cval); }
-            } else {
-                // finite_on_domain() proved the divisor keeps one sign (and stays away from 0) on the
-                // whole domain, so the quotient is monotone in each operand: extremes at the corners
-                const std::string t = "d" + std::to_string(i);
-                pre = "    const float " + t + "a = " + L(n.a) + " / " + L(n.b) + ", " + t + "b = " + L(n.a) + " / " + H(n.b) + ", " +
-                      t + "c = " + H(n.a) + " / " + L(n.b) + ", " + t + "d = " + H(n.a) + " / " + H(n.b) + ";\n";
-                lo = "__builtin_fminf(__builtin_fminf(" + t + "a, " + t + "b), __builtin_fminf(" + t + "c, " + t + "d))";
-                hi = "__builtin_fmaxf(__builtin_fmaxf(" + t + "a, " + t + "b), __builtin_fmaxf(" + t + "c, " + t + "d))";
-            }
-            break;
-        }
-        case NodeOp::POWI: {
-            if (n.ipow == 0 || n.ipow == 1) return std::string();
-            std::snprintf(buf, sizeof buf, "mc_pow_int<%d>", n.ipow);
-            const std::string pw = buf;
-            if (n.ipow < 0) {
-                // base keeps one sign and stays away from 0 (finite_on_domain): x^-n decreases in |x|
-                if ((-n.ipow) % 2 == 0) {
-                    pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
-                          "b = __builtin_fabsf(" + H(n.a) + ");\n";
-                    lo = pw + "(__builtin_fmaxf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
-                    hi = pw + "(__builtin_fminf(q" + std::to_string(i) + "a, q" + std::to_string(i) + "b))";
-                } else {
-                    lo = pw + "(" + H(n.a) + ")";
-                    hi = pw + "(" + L(n.a) + ")";
-                }
-            } else if (n.ipow % 2 == 0) {
-                pre = "    const float q" + std::to_string(i) + "a = __builtin_fabsf(" + L(n.a) + "), q" + std::to_string(i) +
-                      "b = __builtin_fabsf(" + H(n.a) + ");\n    const float q" + std::to_string(i) + "m = __builtin_fmaxf(q" +
-                      std::to_string(i) + "a, q" + std::to_string(i) + "b), q" + std::to_string(i) + "n = (" + L(n.a) +
-                      " <= 0.0f && " + H(n.a) + " >= 0.0f) ? 0.0f : __builtin_fminf(q" + std::to_string(i) + "a, q" +
-                      std::to_string(i) + "b);\n";
-                if (n.ipow == 2) {
-                    lo = "q" + std::to_string(i) + "n * q" + std::to_string(i) + "n";
-                    hi = "q" + std::to_string(i) + "m * q" + std::to_string(i) + "m";
-                } else {
-                    lo = pw + "(q" + std::to_string(i) + "n)";
-                    hi = pw + "(q" + std::to_string(i) + "m)";
-                }
-            } else {  // odd power: monotone increasing, also as computed (product chain of same-sign factors)
-                lo = pw + "(" + L(n.a) + ")";
-                hi = pw + "(" + H(n.a) + ")";
-            }
-            break;
-        }
-        case NodeOp::SIN: case NodeOp::COS:
-            // mc_sin_iv / mc_cos_iv (mc_kernels.hip): endpoints when no extremum can lie inside, else +-1
-            s += "    float " + l + ", " + h + ";\n    " + (n.op == NodeOp::SIN ? "mc_sin_iv(" : "mc_cos_iv(") + L(n.a) + ", " + H(n.a) +
-                 ", " + l + ", " + h + ");\n";
-            continue;
-        default: return std::string();  // general pow
-        }
-        s += pre;
-        s += "    const float " + l + " = " + lo + ";\n";
-        if (n.op == NodeOp::CONST) s += "    const float " + h + " = " + l + ";\n";
-        else s += "    const float " + h + " = " + hi + ";\n";
+        break;
     }
-    s += "    lo = " + L(p.root) + ";\n    hi = " + H(p.root) + ";\n}\n";
+    case NodeOp::SIN: case NodeOp::COS:
+        // mc_sin_iv / mc_cos_iv (mc_kernels.hip): endpoints when no extremum can lie inside, else +-1
+        s += "    float " + l + ", " + h + ";\n    " + (n.op == NodeOp::SIN ? "mc_sin_iv(" : "mc_cos_iv(") + L(n.a) + ", " + H(n.a) +
+             ", " + l + ", " + h + ");\n";
+        return true;
+    default: return false;  // general pow
+    }
+    s += pre;
+    s += "    const float " + l + " = " + lo + ";\n";
+    if (n.op == NodeOp::CONST) s += "    const float " + h + " = " + l + ";\n";
+    else s += "    const float " + h + " = " + hi + ";\n";
+    return true;
+}
+
+// vector instructions the interval code of node i costs (operands not included)
+int iv_node_cost(const Node& n) {
+    switch (n.op) {
+    case NodeOp::ADD: case NodeOp::SUB: case NodeOp::NEG: return 2;
+    case NodeOp::MUL: return 10;
+    case NodeOp::DIV: return 40;
+    case NodeOp::POWI: return 8 + 8 * (n.ipow < 0 ? -n.ipow : n.ipow);
+    case NodeOp::SIN: case NodeOp::COS: return 60;
+    case NodeOp::POW: return 600;
+    default: return 0;
+    }
+}
+}  // namespace
+
+std::string emit_hip_interval(const Program& p, const char* fname) {
+    std::string s;
+    s += std::string("__device__ __forceinline__ void ") + fname + "(float xl, float xh, float yl, float yh, float zl, float zh, float& lo, float& hi) {\n";
+    s += "    (void)xl; (void)xh; (void)yl; (void)yh; (void)zl; (void)zh;\n";
+    for (size_t i = 0; i < p.nodes.size(); ++i)
+        if (!iv_node(p, i, s)) return std::string();
+    const Node& r = p.nodes[p.root];
+    const char v = r.op == NodeOp::VARX ? 'x' : r.op == NodeOp::VARY ? 'y' : r.op == NodeOp::VARZ ? 'z' : 0;
+    if (v) s += std::string("    lo = ") + v + "l;\n    hi = " + v + "h;\n}\n";
+    else s += "    lo = l" + std::to_string(p.root) + ";\n    hi = h" + std::to_string(p.root) + ";\n}\n";
+    return s;
+}
+
+// The same enclosure in two stages, for the classify walk: the sub-expressions that depend on y ONLY and are expensive
+// (sin / cos, divisions, higher powers) are evaluated once per tile row (mc_f_iv_y, lane = row) and the rest per lane
+// box from those values (mc_f_iv_rest).  The walk's x and z boxes do not change from row to row, so the compiler hoists
+// their share by itself; y's it cannot (the row is a loop variable).  "" when nothing is worth staging.
+std::string emit_hip_interval_staged(const Program& p, int min_cost) {
+    const size_t n = p.nodes.size();
+    std::vector<char> used_outside(n, 0);   // some user depends on more than y, or the node is the root
+    for (size_t i = 0; i < n; ++i) {
+        const Node& nd = p.nodes[i];
+        if (nd.deps == 2) continue;
+        if (nd.a >= 0) used_outside[nd.a] = 1;
+        if (nd.b >= 0) used_outside[nd.b] = 1;
+    }
+    used_outside[p.root] = 1;
+    // cost of a node's whole y-only cone (each node once)
+    auto cone = [&](size_t root, std::vector<char>& in) {
+        in.assign(n, 0);
+        in[root] = 1;
+        int c = 0;
+        for (size_t i = root + 1; i-- > 0;) {
+            if (!in[i]) continue;
+            c += iv_node_cost(p.nodes[i]);
+            if (p.nodes[i].a >= 0) in[p.nodes[i].a] = 1;
+            if (p.nodes[i].b >= 0) in[p.nodes[i].b] = 1;
+        }
+        return c;
+    };
+    std::vector<int> hoisted;
+    std::vector<char> in, ystage(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const Node& nd = p.nodes[i];
+        if (nd.deps != 2 || !used_outside[i] || nd.op == NodeOp::VARY) continue;
+        if (cone(i, in) < min_cost) continue;
+        hoisted.push_back((int)i);
+        for (size_t k = 0; k < n; ++k) ystage[k] = ystage[k] | in[k];
+    }
+    if (hoisted.empty() || hoisted.size() > 8) return std::string();
+    std::string s = "#define MC_IV_NY " + std::to_string(2 * hoisted.size()) + "\n";
+    s += "__device__ __forceinline__ void mc_f_iv_y(float yl, float yh, float (&Y)[MC_IV_NY]) {\n";
+    for (size_t i = 0; i < n; ++i)
+        if (ystage[i] && !iv_node(p, i, s)) return std::string();
+    for (size_t k = 0; k < hoisted.size(); ++k)
+        s += "    Y[" + std::to_string(2 * k) + "] = l" + std::to_string(hoisted[k]) + "; Y[" + std::to_string(2 * k + 1) + "] = h" +
+             std::to_string(hoisted[k]) + ";\n";
+    s += "}\n";
+    // the rest: everything the root needs, cut at the hoisted nodes
+    std::vector<char> need(n, 0), is_h(n, 0);
+    for (int h : hoisted) is_h[h] = 1;
+    need[p.root] = 1;
+    for (size_t i = n; i-- > 0;) {
+        if (!need[i] || is_h[i]) continue;
+        if (p.nodes[i].a >= 0) need[p.nodes[i].a] = 1;
+        if (p.nodes[i].b >= 0) need[p.nodes[i].b] = 1;
+    }
+    s += "__device__ __forceinline__ void mc_f_iv_rest(float xl, float xh, float yl, float yh, float zl, float zh, const float (&Y)[MC_IV_NY], "
+         "float& lo, float& hi) {\n    (void)xl; (void)xh; (void)yl; (void)yh; (void)zl; (void)zh;\n";
+    for (size_t k = 0; k < hoisted.size(); ++k)
+        s += "    const float l" + std::to_string(hoisted[k]) + " = Y[" + std::to_string(2 * k) + "], h" + std::to_string(hoisted[k]) + " = Y[" +
+             std::to_string(2 * k + 1) + "];\n";
+    for (size_t i = 0; i < n; ++i)
+        if (need[i] && !is_h[i] && !iv_node(p, i, s)) return std::string();
+    const Node& r = p.nodes[p.root];
+    const char v = r.op == NodeOp::VARX ? 'x' : r.op == NodeOp::VARY ? 'y' : r.op == NodeOp::VARZ ? 'z' : 0;
+    if (v) s += std::string("    lo = ") + v + "l;\n    hi = " + v + "h;\n}\n";
+    else s += "    lo = l" + std::to_string(p.root) + ";\n    hi = h" + std::to_string(p.root) + ";\n}\n";
     return s;
 }
 

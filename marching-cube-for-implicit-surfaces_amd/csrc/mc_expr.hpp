@@ -67,6 +67,13 @@ std::string emit_hip(const Program& p, const char* fname = "mc_f");
 // without sampling them.  Returns "" when the program uses an operation it cannot bound.
 std::string emit_hip_interval(const Program& p, const char* fname = "mc_f_iv");
 
+// The same enclosure split for the classify walk, whose boxes change only in y from one step to the next:
+// `#define MC_IV_NY n`, `mc_f_iv_y(yl, yh, Y)` (the expensive sub-expressions of y alone: sin / cos, divisions, powers
+// above 2 -- evaluated once per tile ROW) and `mc_f_iv_rest(xl,xh,yl,yh,zl,zh, Y, lo, hi)` (everything else, from Y).
+// Composition of the two == emit_hip_interval's function, operation for operation.  "" when no sub-expression of y alone
+// costs at least min_cost vector instructions to bound.
+std::string emit_hip_interval_staged(const Program& p, int min_cost = 40);
+
 // Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
 float eval_host(const Program& p, float x, float y, float z);
 

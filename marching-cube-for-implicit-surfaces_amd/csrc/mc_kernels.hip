@@ -887,15 +887,46 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         // lane listed needlessly just yields uniform codes and no record).
         rowPend = rowsValid & ~cull;
         const u64 lanesIn = __ballot(x0 < n1);  // lanes that hold cells of the grid (a ragged last chunk has fewer)
+#ifdef MC_IV_NY
+        // f has expensive sub-expressions of y alone (sin / cos ...): their enclosures are computed ONCE per tile, lane =
+        // row (mc_f_iv_y), and each step of the loop below only reads its row's values (v_readlane) and combines them
+        // with the lane's x and z parts, which the compiler keeps across the loop (mc_f_iv_rest).  The pairing is the
+        // loop's, in closed form: inside a run of undecided rows the 1st, 3rd, ... are heads, a head pairs with the row
+        // above it when that one is undecided too.
+        const u64 below = ~rowPend & ((1ull << lane) - 1ull);
+        const int runlen = below ? lane - (63 - __builtin_clzll(below)) - 1 : lane;
+        const bool headL = ((rowPend >> lane) & 1ull) && !(runlen & 1);
+        const bool pairL = headL && (((rowPend >> 1) >> lane) & 1ull);
+        float Yv[MC_IV_NY];
+        {
+            const float y1 = __shfl_down(yv, 1, 64), y2 = __shfl_down(yv, 2, 64);
+            const float yt = pairL ? y2 : y1;
+            mc_f_iv_y(__builtin_fminf(yv, yt), __builtin_fmaxf(yv, yt), Yv);
+        }
+        const u64 pairs = __ballot(pairL);
+        u64 mu = __ballot(headL);
+#else
         u64 mu = rowPend;
+#endif
         while (mu) {
             const int j = __builtin_ctzll(mu);
             mu &= mu - 1ull;
+#ifdef MC_IV_NY
+            const int pair = (int)((pairs >> j) & 1ull);
+#else
             const int pair = (int)((mu >> ((j + 1) & 63)) & 1ull);  // row j+1 is undecided too (j + 1 < ny then)
             if (pair) mu &= mu - 1ull;
+#endif
             const float ya = readlane_f(yv, j), yb = readlane_f(yv, j + 1 + pair);
             float lo, hi;
+#ifdef MC_IV_NY
+            float Yu[MC_IV_NY];
+#pragma unroll
+            for (int k = 0; k < MC_IV_NY; ++k) Yu[k] = readlane_f(Yv[k], j);
+            mc_f_iv_rest(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, Yu, lo, hi);
+#else
             mc_f_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, lo, hi);
+#endif
 #ifdef MC_CONS
             bool allok, dead;
             mc_ok_iv(lxl, lxh, __builtin_fminf(ya, yb), __builtin_fmaxf(ya, yb), zl, zh, allok, dead);

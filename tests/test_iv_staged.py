@@ -1,0 +1,126 @@
+"""CPU: the generated interval code (mc_expr.cpp: emit_hip_interval / emit_hip_interval_staged) compiled as HOST code.
+
+The classify walk proves rows and lanes uniform from mc_f_iv without sampling them, and -- for equations with expensive
+sub-expressions of y alone (sin / cos, divisions, powers) -- from the two-stage form mc_f_iv_y + mc_f_iv_rest.  Checked here,
+on random boxes: (1) the staged form returns the same bits as the whole one; (2) every value mc_f computes at points of a
+box lies inside the enclosure (the property the culling's exactness rests on)."""
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+GYROID = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)"
+STAGED = [GYROID, "sin(3y)*x+z*z-0.2", "x^2+z^2-1/(y*y+1.5)", "x*y^5+z^2-0.3", "cos(y)+cos(2y)*x-z", "sin(x)+sin(y)+sin(z)",
+          "x/(y+3)+y^4*z-0.1", "x*x+z+((y-2.5)^-3)*cos(y)"]
+NOT_STAGED = ["x^2+y^2+z^2-1", "x*y+z", "x*x+z+(y-2.5)^-3", "sin(x)*y+z"]
+
+HARNESS = r'''
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#define __device__
+#define __forceinline__ inline
+#define MC_TRIG_FN static inline
+#include "mc_trig.h"
+static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+@@PRELUDE@@
+@@GENERATED@@
+int main() {
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+    const float radius = @@RADIUS@@f;
+    long bad_stage = 0, bad_encl = 0;
+    for (int it = 0; it < 20000; ++it) {
+        float b[6];
+        const float w = (it % 3 == 0) ? 0.004f : (it % 3 == 1) ? 0.05f : 0.6f;   // cell-sized, lane-sized and chunk-sized boxes
+        for (int a = 0; a < 3; ++a) {
+            const float c = U(rng) * radius, h = std::fabs(U(rng)) * w * radius;
+            b[2 * a] = std::fmax(c - h, -radius);      // the enclosure is only claimed inside the domain finite_on_domain() checked
+            b[2 * a + 1] = std::fmin(c + h, radius);
+        }
+        float lo, hi;
+        mc_f_iv(b[0], b[1], b[2], b[3], b[4], b[5], lo, hi);
+#ifdef MC_IV_NY
+        float Y[MC_IV_NY], lo2, hi2;
+        mc_f_iv_y(b[2], b[3], Y);
+        mc_f_iv_rest(b[0], b[1], b[2], b[3], b[4], b[5], Y, lo2, hi2);
+        if (std::memcmp(&lo, &lo2, 4) || std::memcmp(&hi, &hi2, 4)) ++bad_stage;
+#endif
+        for (int k = 0; k < 12; ++k) {
+            float q[3];
+            for (int a = 0; a < 3; ++a) {
+                const float t = k < 8 ? (float)((k >> a) & 1) : 0.5f * (U(rng) + 1.0f);   // the 8 corners, then interior points
+                q[a] = b[2 * a] + t * (b[2 * a + 1] - b[2 * a]);
+                if (q[a] < b[2 * a]) q[a] = b[2 * a];
+                if (q[a] > b[2 * a + 1]) q[a] = b[2 * a + 1];
+            }
+            const float v = mc_f(q[0], q[1], q[2]);
+            if (!(v >= lo && v <= hi)) ++bad_encl;
+        }
+    }
+#ifdef MC_IV_NY
+    std::printf("staged %d bad_stage %ld bad_encl %ld\n", MC_IV_NY, bad_stage, bad_encl);
+#else
+    std::printf("staged 0 bad_stage %ld bad_encl %ld\n", bad_stage, bad_encl);
+#endif
+    return 0;
+}
+'''
+
+
+def prelude():
+    src = (ROOT / "marching-cube-for-implicit-surfaces_amd" / "csrc" / "mc_kernels.hip").read_text()
+    a = src.index("// ------------------------------------------------------------------ power rule P1")
+    b = src.index("//@@MC_F_BEGIN")
+    return src[a:b].replace("__attribute__((noinline))", "")
+
+
+def run_host(mc, tmp_path, eq, radius):
+    gen = mc.expr_dump(eq)
+    assert "mc_f_iv(" in gen, "no enclosure generated"
+    cpp = tmp_path / "iv.cpp"
+    cpp.write_text(HARNESS.replace("@@PRELUDE@@", prelude()).replace("@@GENERATED@@", gen).replace("@@RADIUS@@", repr(radius)))
+    exe = tmp_path / "iv"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", str(cpp), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
+    m = re.match(r"staged (\d+) bad_stage (\d+) bad_encl (\d+)", out)
+    assert m, out
+    return tuple(int(g) for g in m.groups())
+
+
+@pytest.fixture()
+def trig(mc):
+    old = mc.set_extensions(mc.EXT_TRIG)
+    yield
+    mc.set_extensions(old)
+
+
+@pytest.mark.parametrize("eq", STAGED)
+def test_staged_enclosure_equals_whole_and_encloses(mc, trig, tmp_path, eq):
+    ny, bad_stage, bad_encl = run_host(mc, tmp_path, eq, 2.0)
+    assert ny >= 2 and ny % 2 == 0          # one [lo, hi] pair per hoisted sub-expression of y
+    assert bad_stage == 0 and bad_encl == 0
+
+
+@pytest.mark.parametrize("eq", NOT_STAGED)
+def test_cheap_y_parts_are_not_staged(mc, trig, tmp_path, eq):
+    """y^2, a*y and the like stay in the one-stage enclosure (the headline sphere's kernel is unchanged)."""
+    assert "MC_IV_NY" not in mc.expr_dump(eq)
+    ny, bad_stage, bad_encl = run_host(mc, tmp_path, eq, 2.0)
+    assert ny == 0 and bad_encl == 0
+
+
+def test_gyroid_stages_sin_and_cos_of_y(mc, trig):
+    src = mc.expr_dump(GYROID)
+    assert "#define MC_IV_NY 4" in src
+    ypart = src[src.index("void mc_f_iv_y("):src.index("void mc_f_iv_rest(")]
+    assert ypart.count("mc_sin_iv(yl, yh") == 1 and ypart.count("mc_cos_iv(yl, yh") == 1
+    rest = src[src.index("void mc_f_iv_rest("):]
+    assert "yl" not in rest.split("{", 1)[1].replace("(void)yl; (void)yh;", "")   # the rest reads y only through Y[]
