@@ -244,163 +244,185 @@ extern "C" __global__ __launch_bounds__(256) void mc_pack_codes(const u8* __rest
 
 
 // =============================================================== seed mode (Marching::seed_mode, marching.cpp:42-137, :310-331)
-// The reference walks breadth-first from the cell that contains the seed to the face neighbours across every face
-// that carries an intersection.  Here the dense sweep has already classified every cell, so the walk runs over the
-// code volume, in one launch (mc_seed_walk); mc_seed_filter then removes the triangles of unvisited cells from the
-// records before the scan and the emit kernel run.  Cell id = (z*n1 + y)*n1 + x.
-#include "../../include/mc_tables_data.h"
+// The reference walks breadth-first from the cell that contains the seed to the face neighbours across every face that
+// carries an intersection, and emits the cells it reaches.  What it reaches is a CONNECTED COMPONENT of the graph whose
+// nodes are the cells with surface and whose edges are the faces with corners on both sides of iso (such a face makes both
+// its cells surface cells, so the relation is symmetric) -- and the dense sweep has already listed exactly those cells: the
+// records.  So instead of a walk (whose ~2 N dependent hops cost 14 ms at 1025^3, whatever the width of the machine) the
+// component is LABELLED: a lock-free union-find over record indices (mc_cc_link: every record hooks itself to its +x, +y,
+// +z neighbours across mixed faces; roots only ever decrease), a flatten pass, the seed cell's root (mc_cc_seed), and
+// mc_seed_filter then takes the triangles of every other component's records away before the scan and the emit kernel run.
+// Order: the reference emits in visitation order; here the cells come out in sweep order (set-equal).
+//
+// Bounds (marching.cpp:84-86): a move may only reach a cell whose three indices are all <= imax (x0 + 0.5*step <= 1); a
+// cell beyond that is never entered, so it links to nothing -- it can only be emitted as the seed's own cell, whose
+// in-bounds neighbours mc_cc_seed then adds as further roots.
 
-__device__ __forceinline__ u32 seed_code(const u8* codes, const u32* tail, u64 pitch, int n1, int main_cells, int x, int y, int z) {
-    const u64 row = (u64)z * (u64)n1 + (u64)y;
-    return x < main_cells ? (u32)codes[row * pitch + (u64)x] : (tail[row] >> (8 * (x - main_cells))) & 0xFFu;
-}
-
-// counters of the walk, one per 128-byte line: [0] next queue slot to take, [32] slots handed out to producers, [64] cells
-// fully expanded, [96] a lane gave up (spin bound)
-extern "C" __global__ __launch_bounds__(64) void mc_seed_init(u32* __restrict__ visited, u32* __restrict__ queue, u32* __restrict__ ctr,
-                                                    u32 cell) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        visited[cell >> 5] = 1u << (cell & 31u);
-        queue[0] = cell + 1u;  // a queue slot holds cell + 1; 0 = not written yet
-        ctr[0] = 0u;
-        ctr[32] = 1u;
-        ctr[64] = 0u;
-        ctr[96] = 0u;
-    }
-}
-
-// The whole walk in ONE launch: an asynchronous work list instead of one launch per breadth-first level (the order in
-// which the cells of a component are reached does not change the component).  A WAVE takes 64 consecutive queue slots at a
-// time (one atomic add on the head per 64 cells: a single word takes ~90 atomics per microsecond, and 5 M cells were
-// 40 ms of them when every lane dequeued for itself); lane l polls slot base + l until a producer has filled it, expands
-// its cell -- for each face that carries an intersection the neighbour is marked in the visited bitmap with atomicOr and
-// kept if it was new --, the wave's new cells get their slots with ONE atomic add on the tail (wave prefix sum) and are
-// stored as cell + 1 (the value is its own "ready" flag), and the expanded cells are counted with one add.  The walk is
-// over when every appended cell has been expanded (done == tail: no expansion is running, so nothing more can be
-// appended); a lane that finds that, and whose slot lies beyond the tail, is through; a wave leaves when all its lanes are.
-// One loop with a wave-uniform exit and plain if / else inside: a lane that waits must never sit in an inner spin loop of
-// its own -- in lockstep the lane of the same wave that holds the work those lanes wait for would never get its turn.
-// imax: the largest cell index a move may reach (marching.cpp:84-86: x0 + 0.5*step <= 1); the lower bound is index 0.
-#define SEED_SPIN_MAX (1u << 21)  // ~1 s of polling: the whole walk takes milliseconds
-extern "C" __global__ __launch_bounds__(64) void mc_seed_walk(const u8* __restrict__ codes, const u32* __restrict__ tail, u64 pitch, int n1,
-                                                    int main_cells, int imax, u32* __restrict__ visited, u32* queue, u32 qcap, u32* ctr) {
-    constexpr unsigned short kfc[6] = MC_FACE_CORNER_INIT;  // marching_lookup.h:25-32
-    const u32 lane = threadIdx.x & 63u;
-    u32 base = 0u;
-    if (lane == 0u) base = atomicAdd(&ctr[0], 64u);
-    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-    bool consumed = false;  // this lane's slot of the current block has been expanded
-    bool through = false;   // ... will never be filled: the walk is over
-    u32 spins = 0;
+// path halving; concurrent hooks only ever replace a parent by one of its ancestors
+__device__ __forceinline__ u32 cc_find(u32* parent, u32 r) {
     for (;;) {
-        const u32 my = base + lane;
-        u32 v = 0u;
-        if (!consumed && !through && my < qcap) v = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool have = v != 0u;
-        u32 fresh[6];
-        u32 nfresh = 0u;
-        if (have) {
-            const u32 cell = v - 1u;
-            const int x = (int)(cell % (u32)n1), y = (int)((cell / (u32)n1) % (u32)n1), z = (int)(cell / ((u32)n1 * (u32)n1));
-            const u32 code = seed_code(codes, tail, pitch, n1, main_cells, x, y, z);
-            const bool surf = code != 0u && code != 255u;  // (a cell without surface has an empty edge list: marching.cpp:508-510)
+        const u32 p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == r) return r;
+        const u32 gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp == p) return p;
+        __hip_atomic_store(&parent[r], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = gp;
+    }
+}
+// the larger root is hooked under the smaller one; a failed CAS means somebody else hooked it first: find again
+__device__ __forceinline__ void cc_union(u32* parent, u32 a, u32 b) {
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const u32 t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&parent[a], a, b) == a) return;
+    }
+}
+// index of the record of cell `cellx` of segment seg (records of a segment ascend in cellx), ~0u when it has none
+__device__ __forceinline__ u32 cc_lookup(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32 seg, u32 cellx) {
+    const uint2 cb = segcb[seg];
+    const u32 act = cb.x >> 16;
+    u32 lo = 0u, hi = act;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if ((recs[cb.y + mid] & 0xFFu) < cellx) lo = mid + 1u;
+        else hi = mid;
+    }
+    return (lo < act && (recs[cb.y + lo] & 0xFFu) == cellx) ? cb.y + lo : 0xFFFFFFFFu;
+}
+// corners of the +x / +y / +z face of a cell (corner i = bit i of the cube code, marching.cpp:471-472): the face carries an
+// intersection iff its corners are not all on one side (marching.cpp:62-69)
+#define CC_FACE_PX 0x66u
+#define CC_FACE_PY 0xCCu
+#define CC_FACE_PZ 0xF0u
+__device__ __forceinline__ bool cc_mixed(u32 code, u32 face) { return (code & face) != 0u && (code & face) != face; }
+
+// One wave per GROUP of 64 segments, one lane per record (64 at a time): mode 0 parent[r] = r; mode 1 the unions;
+// mode 2 parent[r] = root(r).
+extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32* parent, u32 nseg,
+                                                   int nchunk, int n1, int imax, const u32* __restrict__ overflow, int mode) {
+    __shared__ u32 s_off[4][65];
+    __shared__ u32 s_first[4][64];
+    if (overflow[0] != 0u) return;  // a record region overflowed: the host sweeps again with a larger buffer
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u32 grp = blockIdx.x * 4u + w;
+    const u32 seg0 = grp * 64u;
+    if (seg0 >= nseg) return;  // whole wave
+    u32 act = 0u, first = 0u;
+    if (seg0 + lane < nseg) {
+        const uint2 cb = segcb[seg0 + lane];
+        act = cb.x >> 16;
+        first = cb.y;
+    }
+    u32 incl = act;
 #pragma unroll
-            for (int f = 0; f < 6; ++f) {
-                // the face carries an intersection iff its four corners are not all on one side (marching.cpp:62-69)
-                int ones = 0, bx = 0, by = 0, bz = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)incl, o, 64);
+        if (lane >= (u32)o) incl += t;
+    }
+    s_off[w][lane + 1u] = incl;
+    if (lane == 0u) s_off[w][0] = 0u;
+    s_first[w][lane] = first;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    for (u32 base = 0u; base < total; base += 64u) {
+        const u32 k = base + lane;
+        if (k >= total) continue;
+        // owning segment: the last one whose offset is <= k
+        u32 s = 0u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = (kfc[f] >> (4 * k)) & 0xF;
-                    ones += (code >> c) & 1u;
-                    bx += (0x66 >> c) & 1;
-                    by += (0xCC >> c) & 1;
-                    bz += c >> 2;
-                }
-                // marching_lookup.h:43-50 cube_face_normal = the axis on which the face's corners agree
-                const int nx = x + (bx == 4 ? 1 : bx == 0 ? -1 : 0), ny = y + (by == 4 ? 1 : by == 0 ? -1 : 0),
-                          nz = z + (bz == 4 ? 1 : bz == 0 ? -1 : 0);
-                const bool go = surf && ones != 0 && ones != 4 && nx >= 0 && ny >= 0 && nz >= 0 && nx <= imax && ny <= imax && nz <= imax;  // marching.cpp:84-86
-                fresh[f] = 0xFFFFFFFFu;
-                if (go) {
-                    const u32 nc = ((u32)nz * (u32)n1 + (u32)ny) * (u32)n1 + (u32)nx;
-                    const u32 bit = 1u << (nc & 31u);
-                    if (!(atomicOr(&visited[nc >> 5], bit) & bit)) {  // marching.cpp:89-97: queue it unless it is in the set already
-                        fresh[f] = nc;
-                        ++nfresh;
-                    }
-                }
+        for (u32 st = 32u; st >= 1u; st >>= 1)
+            if (s + st < 64u && s_off[w][s + st] <= k) s += st;
+        const u32 r = s_first[w][s] + (k - s_off[w][s]);
+        if (mode == 0) {
+            parent[r] = r;
+            continue;
+        }
+        if (mode == 2) {
+            const u32 root = cc_find(parent, r);
+            __hip_atomic_store(&parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const u32 seg = seg0 + s;
+        const u32 rec = recs[r];
+        const u32 cellx = rec & 0xFFu, code = (rec >> 8) & 0xFFu;
+        const u32 rowidx = seg / (u32)nchunk, ch = seg - rowidx * (u32)nchunk;
+        const int x = (int)(ch * 256u + cellx), y = (int)(rowidx % (u32)n1), z = (int)(rowidx / (u32)n1);
+        if (x > imax || y > imax || z > imax) continue;  // never entered by a move
+        if (cc_mixed(code, CC_FACE_PX) && x + 1 <= imax) {
+            u32 rn = 0xFFFFFFFFu;
+            if (cellx < 255u) {  // same segment: the next record, if it is that cell's
+                if (k + 1u < s_off[w][s + 1u] && (recs[r + 1u] & 0xFFu) == cellx + 1u) rn = r + 1u;
+            } else if ((int)ch + 1 < nchunk) {
+                rn = cc_lookup(recs, segcb, seg + 1u, 0u);
             }
-            consumed = true;
-            spins = 0;
+            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
         }
-        // the wave's new cells: one atomic add on the tail, the slots handed out by a prefix sum
-        u32 incl = nfresh;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = (u32)__shfl_up((int)incl, o, 64);
-            if (lane >= (u32)o) incl += t;
+        if (cc_mixed(code, CC_FACE_PY) && y + 1 <= imax && y + 1 < n1) {
+            const u32 rn = cc_lookup(recs, segcb, seg + (u32)nchunk, cellx);
+            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
         }
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        const u64 worked = __ballot(have);
-        if (total) {
-            u32 tb = 0u;
-            if (lane == 0u) tb = atomicAdd(&ctr[32], total);
-            tb = (u32)__builtin_amdgcn_readfirstlane((int)tb);
-            u32 slot = tb + incl - nfresh;
-#pragma unroll
-            for (int f = 0; f < 6; ++f)
-                if (have && fresh[f] != 0xFFFFFFFFu) {
-                    if (slot < qcap) __hip_atomic_store(&queue[slot], fresh[f] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ++slot;
-                }
-            // (slots beyond the list's end -- cannot happen, it holds every record -- are counted as done right away so
-            // that the walk still ends)
-            const u32 lost = tb + total > qcap ? min(total, tb + total - qcap) : 0u;
-            if (lost && lane == 0u) atomicAdd(&ctr[64], lost);
-        }
-        // after the appends: done == tail then really means "nothing is running"
-        if (worked && lane == 0u) atomicAdd(&ctr[64], (u32)__builtin_popcountll(worked));
-        if (!have && !consumed && !through) {
-            const u32 done = __hip_atomic_load(&ctr[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 tl = __hip_atomic_load(&ctr[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((done == tl && my >= tl) || my >= qcap) through = true;
-            if (++spins > SEED_SPIN_MAX) {
-                ctr[96] = 1u;
-                through = true;
-            }
-        }
-        const u64 open = __ballot(!consumed && !through);
-        if (open == 0ull) {
-            if (__ballot(through)) break;  // the end of the list lies inside (or before) this block: nothing comes after it
-            // every slot of the block has been expanded: the next 64
-            u32 nb = 0u;
-            if (lane == 0u) nb = atomicAdd(&ctr[0], 64u);
-            base = (u32)__builtin_amdgcn_readfirstlane((int)nb);
-            consumed = false;
-        } else if (worked == 0ull) {
-            __builtin_amdgcn_s_sleep(8);
+        if (cc_mixed(code, CC_FACE_PZ) && z + 1 <= imax && z + 1 < n1) {
+            const u32 rn = cc_lookup(recs, segcb, seg + (u32)nchunk * (u32)n1, cellx);
+            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
         }
     }
 }
 
-// one lane per segment: records of unvisited cells lose their triangles; the segment's triangle prefix, its
+// The roots the seed reaches (after the flatten pass: parent[r] IS the root): roots[0] = how many, roots[1..7].  The seed's
+// own cell is always visited (marching.cpp:310-316); if it lies beyond imax it is linked to nothing, and the cells its
+// expansion enters are its in-bounds neighbours across mixed faces.
+extern "C" __global__ __launch_bounds__(64) void mc_cc_seed(const u32* __restrict__ recs, const uint2* __restrict__ segcb, const u32* __restrict__ parent,
+                                                  u32* __restrict__ roots, int nchunk, int n1, int imax, int sx, int sy, int sz, int inside,
+                                                  const u32* __restrict__ overflow) {
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    u32 n = 0u;
+    if (inside && overflow[0] == 0u) {
+        const u32 seg = ((u32)sz * (u32)n1 + (u32)sy) * (u32)nchunk + (u32)(sx >> 8);
+        const u32 r = cc_lookup(recs, segcb, seg, (u32)(sx & 255));
+        if (r != 0xFFFFFFFFu) {  // (a seed cell without surface reaches nothing: its edge list is empty, marching.cpp:508-510)
+            roots[++n] = parent[r];
+            if (sx > imax || sy > imax || sz > imax) {
+                const u32 code = (recs[r] >> 8) & 0xFFu;
+                const u32 faces[6] = {CC_FACE_PX, 0xFFu ^ CC_FACE_PX, CC_FACE_PY, 0xFFu ^ CC_FACE_PY, CC_FACE_PZ, 0xFFu ^ CC_FACE_PZ};
+                const int dx[6] = {1, -1, 0, 0, 0, 0}, dy[6] = {0, 0, 1, -1, 0, 0}, dz[6] = {0, 0, 0, 0, 1, -1};
+                for (int f = 0; f < 6; ++f) {
+                    const int nx = sx + dx[f], ny = sy + dy[f], nz = sz + dz[f];
+                    if (!cc_mixed(code, faces[f]) || nx < 0 || ny < 0 || nz < 0 || nx > imax || ny > imax || nz > imax) continue;
+                    const u32 rn = cc_lookup(recs, segcb, ((u32)nz * (u32)n1 + (u32)ny) * (u32)nchunk + (u32)(nx >> 8), (u32)(nx & 255));
+                    if (rn != 0xFFFFFFFFu) roots[++n] = parent[rn];
+                }
+            }
+        }
+    }
+    roots[0] = n;
+}
+
+// one lane per segment: records outside the seed's component lose their triangles; the segment's triangle prefix, its
 // counts and the group sums are rebuilt
-extern "C" __global__ __launch_bounds__(256) void mc_seed_filter(u32* __restrict__ recs, uint2* __restrict__ segcb, const u32* __restrict__ visited,
-                                                       u32 nseg, int nchunk, int n1, u64* __restrict__ grpsum,
+extern "C" __global__ __launch_bounds__(256) void mc_seed_filter(u32* __restrict__ recs, uint2* __restrict__ segcb, const u32* __restrict__ parent,
+                                                       const u32* __restrict__ roots, u32 nseg, u64* __restrict__ grpsum,
                                                        const u32* __restrict__ overflow) {
     const u32 seg = blockIdx.x * 256u + threadIdx.x;
     if (seg >= nseg || overflow[0] != 0u) return;
     const uint2 cb = segcb[seg];
     const u32 act = cb.x >> 16;
     if (act == 0u) return;
-    const u32 rowidx = seg / (u32)nchunk, ch = seg - rowidx * (u32)nchunk;
-    const u32 rowcell = rowidx * (u32)n1 + ch * 256u;  // id of the segment's first cell (rowidx = z*n1 + y)
+    const u32 nroots = roots[0];
     u32 tris = 0u;
     for (u32 k = 0; k < act; ++k) {
         u32 r = recs[cb.y + k];
-        const u32 cell = rowcell + (r & 0xFFu);
         u32 nt = (r >> 17) & 7u;
-        if (!((visited[cell >> 5] >> (cell & 31u)) & 1u)) nt = 0u;
+        const u32 root = parent[cb.y + k];
+        bool keep = false;
+        for (u32 i = 1u; i <= nroots; ++i) keep = keep || root == roots[i];
+        if (!keep) nt = 0u;
         r = (r & 0x1FFFFu) | (nt << 17) | (tris << 20);
         recs[cb.y + k] = r;
         tris += nt;
