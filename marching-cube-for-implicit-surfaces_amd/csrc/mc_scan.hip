@@ -269,6 +269,16 @@ __device__ __forceinline__ u32 cc_find(u32* parent, u32 r) {
         r = gp;
     }
 }
+// the same without writing: the flatten pass must be the only writer of what it publishes -- a concurrent path-halving
+// store (an ancestor read a moment ago) could land on top of a root the record's own lane has just stored, and the filter
+// would then take the record for a member of another component (seen: a few cells of 4.9 M dropped, differently every run)
+__device__ __forceinline__ u32 cc_find_ro(const u32* parent, u32 r) {
+    for (;;) {
+        const u32 p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == r) return r;
+        r = p;
+    }
+}
 // the larger root is hooked under the smaller one; a failed CAS means somebody else hooked it first: find again
 __device__ __forceinline__ void cc_union(u32* parent, u32 a, u32 b) {
     for (;;) {
@@ -302,17 +312,60 @@ __device__ __forceinline__ u32 cc_lookup(const u32* __restrict__ recs, const uin
 #define CC_FACE_PZ 0xF0u
 __device__ __forceinline__ bool cc_mixed(u32 code, u32 face) { return (code & face) != 0u && (code & face) != face; }
 
-// One wave per GROUP of 64 segments, one lane per record (64 at a time): mode 0 parent[r] = r; mode 1 the unions;
-// mode 2 parent[r] = root(r).
-extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32* parent, u32 nseg,
-                                                   int nchunk, int n1, int imax, const u32* __restrict__ overflow, int mode) {
-    __shared__ u32 s_off[4][65];
-    __shared__ u32 s_first[4][64];
-    if (overflow[0] != 0u) return;  // a record region overflowed: the host sweeps again with a larger buffer
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u32 grp = blockIdx.x * 4u + w;
-    const u32 seg0 = grp * 64u;
-    if (seg0 >= nseg) return;  // whole wave
+// two look-ups side by side (the +y and the +z neighbour): their binary searches are chains of dependent loads, and a
+// wave has nothing else to do meanwhile -- issued together they cost one chain, not two
+__device__ __forceinline__ void cc_lookup2(const u32* __restrict__ recs, const uint2* __restrict__ segcb, bool wa, u32 sega, bool wb, u32 segb,
+                                           u32 cellx, u32& ra, u32& rb) {
+    const uint2 ca = wa ? segcb[sega] : make_uint2(0u, 0u), cb = wb ? segcb[segb] : make_uint2(0u, 0u);
+    const u32 acta = ca.x >> 16, actb = cb.x >> 16;
+    u32 loa = 0u, hia = acta, lob = 0u, hib = actb;
+    while (loa < hia || lob < hib) {
+        const u32 ma = (loa + hia) >> 1, mb = (lob + hib) >> 1;
+        const u32 va = loa < hia ? recs[ca.y + ma] & 0xFFu : 0u, vb = lob < hib ? recs[cb.y + mb] & 0xFFu : 0u;
+        if (loa < hia) {
+            if (va < cellx) loa = ma + 1u;
+            else hia = ma;
+        }
+        if (lob < hib) {
+            if (vb < cellx) lob = mb + 1u;
+            else hib = mb;
+        }
+    }
+    const u32 fa = loa < acta ? recs[ca.y + loa] & 0xFFu : 0x100u, fb = lob < actb ? recs[cb.y + lob] & 0xFFu : 0x100u;
+    ra = fa == cellx ? ca.y + loa : 0xFFFFFFFFu;
+    rb = fb == cellx ? cb.y + lob : 0xFFFFFFFFu;
+}
+
+// ---- the same union-find on a wave's window of records, in LDS (indices = positions in the window)
+__device__ __forceinline__ u32 lds_find(u32* lab, u32 i) {
+    for (;;) {
+        const u32 p = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == i) return i;
+        const u32 gp = __hip_atomic_load(&lab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gp == p) return p;
+        __hip_atomic_store(&lab[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = gp;
+    }
+}
+__device__ __forceinline__ void lds_union(u32* lab, u32 a, u32 b) {
+    for (;;) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) {
+            const u32 t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&lab[a], a, b) == a) return;
+    }
+}
+
+#define CC_WIN 1024u  // records of a group labelled together in LDS (a group of the 1025^3 sphere has ~60, of the gyroid ~250)
+
+// what the two kernels below share: the group's segments (lane = segment), their record offsets inside the group
+// (s_off[0..64]) and first record indices, in LDS; returns the group's record count
+__device__ __forceinline__ u32 cc_group(const uint2* __restrict__ segcb, u32 seg0, u32 nseg, u32 lane, u32* s_off, u32* s_first) {
     u32 act = 0u, first = 0u;
     if (seg0 + lane < nseg) {
         const uint2 cb = segcb[seg0 + lane];
@@ -325,53 +378,160 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         const u32 t = (u32)__shfl_up((int)incl, o, 64);
         if (lane >= (u32)o) incl += t;
     }
-    s_off[w][lane + 1u] = incl;
-    if (lane == 0u) s_off[w][0] = 0u;
-    s_first[w][lane] = first;
+    s_off[lane + 1u] = incl;
+    if (lane == 0u) s_off[0] = 0u;
+    s_first[lane] = first;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-    for (u32 base = 0u; base < total; base += 64u) {
-        const u32 k = base + lane;
-        if (k >= total) continue;
-        // owning segment: the last one whose offset is <= k
-        u32 s = 0u;
+    return (u32)__builtin_amdgcn_readlane((int)incl, 63);
+}
+// segment (0..63) of the group's k-th record: the last one whose offset is <= k
+__device__ __forceinline__ u32 cc_segment_of(const u32* s_off, u32 k) {
+    u32 s = 0u;
 #pragma unroll
-        for (u32 st = 32u; st >= 1u; st >>= 1)
-            if (s + st < 64u && s_off[w][s + st] <= k) s += st;
-        const u32 r = s_first[w][s] + (k - s_off[w][s]);
-        if (mode == 0) {
-            parent[r] = r;
-            continue;
+    for (u32 st = 32u; st >= 1u; st >>= 1)
+        if (s + st < 64u && s_off[s + st] <= k) s += st;
+    return s;
+}
+
+// Step 1, one wave per GROUP of 64 segments (12.8 rows of one layer at 1025 cells per row): the components of the group's
+// own records -- +x links (next record of the segment, or the first record of the next segment of the row) and +y links
+// into the group's later rows -- by a union-find in LDS, CC_WIN records at a time; then every record's global parent is
+// set to its local root.  The global union-find (mc_cc_link) so starts from ~2 sets per group instead of one per record:
+// 30x fewer hooks on the way to the one big component a surface usually is, and trees one level deep.
+extern "C" __global__ __launch_bounds__(256) void mc_cc_local(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32* __restrict__ parent,
+                                                    u32 nseg, int nchunk, int n1, int imax, const u32* __restrict__ overflow) {
+    __shared__ u32 s_off[4][65];
+    __shared__ u32 s_first[4][64];
+    __shared__ u32 s_rec[4][CC_WIN];  // cell | code << 8 | segment << 16
+    __shared__ u32 s_lab[4][CC_WIN];
+    if (overflow[0] != 0u) return;  // a record region overflowed: the host sweeps again with a larger buffer
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u32 seg0 = (blockIdx.x * 4u + w) * 64u;
+    if (seg0 >= nseg) return;  // whole wave
+    u32* const off = s_off[w];
+    u32* const lrec = s_rec[w];
+    u32* const lab = s_lab[w];
+    const u32 total = cc_group(segcb, seg0, nseg, lane, off, s_first[w]);
+    for (u32 win0 = 0u; win0 < total; win0 += CC_WIN) {
+        const u32 n = min(CC_WIN, total - win0);
+        for (u32 i = lane; i < n; i += 64u) {
+            const u32 k = win0 + i;
+            const u32 sg = cc_segment_of(off, k);
+            lrec[i] = (recs[s_first[w][sg] + (k - off[sg])] & 0xFFFFu) | (sg << 16);
+            lab[i] = i;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = lane; i < n; i += 64u) {
+            const u32 v = lrec[i];
+            const u32 cellx = v & 0xFFu, code = (v >> 8) & 0xFFu, sg = v >> 16;
+            const u32 seg = seg0 + sg;
+            const u32 rowidx = seg / (u32)nchunk, ch = seg - rowidx * (u32)nchunk;
+            const int x = (int)(ch * 256u + cellx), y = (int)(rowidx % (u32)n1), z = (int)(rowidx / (u32)n1);
+            if (x > imax || y > imax || z > imax) continue;  // never entered by a move: links to nothing
+            if (cc_mixed(code, CC_FACE_PX) && x + 1 <= imax) {
+                u32 j = 0xFFFFFFFFu;
+                if (cellx < 255u) {
+                    if (i + 1u < n && lrec[i + 1u] == ((v & 0xFFFF0000u) | (lrec[i + 1u] & 0xFF00u) | (cellx + 1u))) j = i + 1u;
+                } else if (sg + 1u < 64u && (int)ch + 1 < nchunk) {
+                    const u32 k2 = off[sg + 1u];
+                    if (k2 < off[sg + 2u] && k2 >= win0 && k2 < win0 + n && (lrec[k2 - win0] & 0xFFu) == 0u) j = k2 - win0;
+                }
+                if (j != 0xFFFFFFFFu) lds_union(lab, i, j);
+            }
+            if (cc_mixed(code, CC_FACE_PY) && y + 1 <= imax && sg + (u32)nchunk < 64u) {
+                const u32 sy = sg + (u32)nchunk;
+                u32 lo = max(off[sy], win0), hi = min(off[sy + 1u], win0 + n);
+                if (lo < hi) {
+                    lo -= win0;
+                    hi -= win0;
+                    const u32 end = hi;
+                    while (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if ((lrec[mid] & 0xFFu) < cellx) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                    if (lo < end && (lrec[lo] & 0xFFu) == cellx) lds_union(lab, i, lo);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = lane; i < n; i += 64u) {
+            u32 root = i;  // (read-only walk: the unions are over)
+            for (;;) {
+                const u32 p = lab[root];
+                if (p == root) break;
+                root = p;
+            }
+            const u32 sg = lrec[i] >> 16, sr = lrec[root] >> 16;
+            parent[s_first[w][sg] + (win0 + i - off[sg])] = s_first[w][sr] + (win0 + root - off[sr]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Step 2 (mode 1), one wave per group, one lane per record (64 at a time): the links mc_cc_local could not see -- +z, +y out
+// of the group, +x out of the group's last segment (and, in a group of more than CC_WIN records, every +y and the links
+// across a window's end) -- as unions on the global parents.  A link is left out when the previous lane's record has the
+// same parent as this one, has a link of the same kind, and the two neighbours have one parent too: equal parents mean
+// one set (sets only merge), so the previous lane's union -- or the one it relied on -- already joins all four.
+// Step 3 (mode 2): parent[r] = root(r).
+extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32* parent, u32 nseg,
+                                                   int nchunk, int n1, int imax, const u32* __restrict__ overflow, int mode) {
+    __shared__ u32 s_off[4][65];
+    __shared__ u32 s_first[4][64];
+    if (overflow[0] != 0u) return;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u32 seg0 = (blockIdx.x * 4u + w) * 64u;
+    if (seg0 >= nseg) return;  // whole wave
+    const u32* const off = s_off[w];
+    const u32 total = cc_group(segcb, seg0, nseg, lane, s_off[w], s_first[w]);
+    const bool single = total <= CC_WIN;
+    for (u32 base = 0u; base < total; base += 64u) {  // (wave-uniform trip count: the shuffles below see every lane)
+        const u32 k = base + lane;
+        const bool valid = k < total;
+        const u32 sg = valid ? cc_segment_of(off, k) : 0u;
+        const u32 r = s_first[w][sg] + (k - off[sg]);
         if (mode == 2) {
-            const u32 root = cc_find(parent, r);
-            __hip_atomic_store(&parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+            if (valid) {
+                const u32 root = cc_find_ro(parent, r);  // (roots are final: mode 1 has completed)
+                __hip_atomic_store(&parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;  // wave-uniform
         }
-        const u32 seg = seg0 + s;
-        const u32 rec = recs[r];
+        const u32 seg = seg0 + sg;
+        const u32 rec = valid ? recs[r] : 0u;
         const u32 cellx = rec & 0xFFu, code = (rec >> 8) & 0xFFu;
         const u32 rowidx = seg / (u32)nchunk, ch = seg - rowidx * (u32)nchunk;
         const int x = (int)(ch * 256u + cellx), y = (int)(rowidx % (u32)n1), z = (int)(rowidx / (u32)n1);
-        if (x > imax || y > imax || z > imax) continue;  // never entered by a move
-        if (cc_mixed(code, CC_FACE_PX) && x + 1 <= imax) {
-            u32 rn = 0xFFFFFFFFu;
-            if (cellx < 255u) {  // same segment: the next record, if it is that cell's
-                if (k + 1u < s_off[w][s + 1u] && (recs[r + 1u] & 0xFFu) == cellx + 1u) rn = r + 1u;
-            } else if ((int)ch + 1 < nchunk) {
-                rn = cc_lookup(recs, segcb, seg + 1u, 0u);
+        const bool inb = valid && x <= imax && y <= imax && z <= imax;  // a cell beyond imax is never entered by a move
+        // the links left to this step, and their far ends
+        u32 rx = 0xFFFFFFFFu, ry, rz;
+        if (inb && cc_mixed(code, CC_FACE_PX) && x + 1 <= imax) {
+            if (cellx < 255u) {
+                if (!single && ((k + 1u) & (CC_WIN - 1u)) == 0u && k + 1u < off[sg + 1u] && (recs[r + 1u] & 0xFFu) == cellx + 1u) rx = r + 1u;
+            } else if ((int)ch + 1 < nchunk && (sg == 63u || !single)) {
+                rx = cc_lookup(recs, segcb, seg + 1u, 0u);
             }
-            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
         }
-        if (cc_mixed(code, CC_FACE_PY) && y + 1 <= imax && y + 1 < n1) {
-            const u32 rn = cc_lookup(recs, segcb, seg + (u32)nchunk, cellx);
-            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
-        }
-        if (cc_mixed(code, CC_FACE_PZ) && z + 1 <= imax && z + 1 < n1) {
-            const u32 rn = cc_lookup(recs, segcb, seg + (u32)nchunk * (u32)n1, cellx);
-            if (rn != 0xFFFFFFFFu) cc_union(parent, r, rn);
-        }
+        const bool wy = inb && cc_mixed(code, CC_FACE_PY) && y + 1 <= imax && (sg + (u32)nchunk >= 64u || !single);
+        const bool wz = inb && cc_mixed(code, CC_FACE_PZ) && z + 1 <= imax;
+        cc_lookup2(recs, segcb, wy, seg + (u32)nchunk, wz, seg + (u32)nchunk * (u32)n1, cellx, ry, rz);
+        // parents, for the test above (any value read is an ancestor; equal ancestors = one set)
+        const u32 none = 0xFFFFFFFFu;
+        const u32 pm = valid ? __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        const u32 px = rx != none ? __hip_atomic_load(&parent[rx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        const u32 py = ry != none ? __hip_atomic_load(&parent[ry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        const u32 pz = rz != none ? __hip_atomic_load(&parent[rz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        const u32 qm = (u32)__shfl_up((int)pm, 1, 64), qx = (u32)__shfl_up((int)px, 1, 64), qy = (u32)__shfl_up((int)py, 1, 64),
+                  qz = (u32)__shfl_up((int)pz, 1, 64);
+        const bool same = lane > 0u && qm == pm;
+        if (rx != none && !(same && qx == px)) cc_union(parent, r, rx);
+        if (ry != none && !(same && qy == py)) cc_union(parent, r, ry);
+        if (rz != none && !(same && qz == pz)) cc_union(parent, r, rz);
     }
 }
 
