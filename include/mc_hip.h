@@ -177,7 +177,9 @@ int mc_set_constraint(mc_context *ctx, int i, const char *lhs, const char *op, f
  * :310-331): those reached from the cell containing the seed across faces that carry an intersection, never past the
  * last cell whose centre lies inside [-1,1] (:84-86).  Differences, DESIGN.md: cells are the dense sweep's lattice cells
  * (the reference re-derives their positions as -1 + k*step, a few ulp off), and the triangles come in sweep order, not in
- * breadth-first order.  Whole-grid sweeps only (z_begin 0, z_end -1); not capturable by mc_graph_build. */
+ * breadth-first order.  (That set is a connected component of the surface cells; it is labelled on the device by a
+ * union-find over the sweep's records, not walked.)  Whole-grid sweeps only (z_begin 0, z_end -1); not capturable by
+ * mc_graph_build. */
 int mc_set_seed(mc_context *ctx, float x, float y, float z);
 int mc_seed_mode(mc_context *ctx, int on);
 int mc_use_constraint(mc_context *ctx, int i, int use);

@@ -473,16 +473,37 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_local(const u32* __restr
     }
 }
 
+// One lane per (pm, pn) pair of the chunk: a 128-slot LDS table claimed with a compare-and-swap; a lane that finds its
+// slot taken yields only if the holder has the very same pair (a colliding pair is simply made twice).
+__device__ __forceinline__ bool cc_leader(u32* tab, u32* key, u32 lane, bool has, u32 pm, u32 pn) {
+    tab[lane] = 0u;
+    tab[lane + 64u] = 0u;
+    key[lane] = pm;
+    key[lane + 64u] = pn;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool lead = has;
+    if (has) {
+        const u32 slot = ((pm * 0x9E3779B1u) ^ (pn * 0x85EBCA77u)) >> 25;
+        const u32 old = atomicCAS(&tab[slot], 0u, lane + 1u);
+        if (old != 0u && key[old - 1u] == pm && key[old + 63u] == pn) lead = false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the table is used again right away)
+    return lead;
+}
+
 // Step 2 (mode 1), one wave per group, one lane per record (64 at a time): the links mc_cc_local could not see -- +z, +y out
 // of the group, +x out of the group's last segment (and, in a group of more than CC_WIN records, every +y and the links
-// across a window's end) -- as unions on the global parents.  A link is left out when the previous lane's record has the
-// same parent as this one, has a link of the same kind, and the two neighbours have one parent too: equal parents mean
-// one set (sets only merge), so the previous lane's union -- or the one it relied on -- already joins all four.
+// across a window's end) -- as unions on the global parents.  Of the chunk's links of one kind only ONE per pair (parent of
+// the record, parent of its neighbour) is made, by whichever lane claims the pair first (cc_leader): equal parents mean
+// one set (sets only merge), so that lane's union already joins all four.
 // Step 3 (mode 2): parent[r] = root(r).
 extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32* parent, u32 nseg,
                                                    int nchunk, int n1, int imax, const u32* __restrict__ overflow, int mode) {
     __shared__ u32 s_off[4][65];
     __shared__ u32 s_first[4][64];
+    __shared__ u32 s_tab[4][128], s_key[4][128];
     if (overflow[0] != 0u) return;
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const u32 seg0 = (blockIdx.x * 4u + w) * 64u;
@@ -526,12 +547,12 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         const u32 px = rx != none ? __hip_atomic_load(&parent[rx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
         const u32 py = ry != none ? __hip_atomic_load(&parent[ry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
         const u32 pz = rz != none ? __hip_atomic_load(&parent[rz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
-        const u32 qm = (u32)__shfl_up((int)pm, 1, 64), qx = (u32)__shfl_up((int)px, 1, 64), qy = (u32)__shfl_up((int)py, 1, 64),
-                  qz = (u32)__shfl_up((int)pz, 1, 64);
-        const bool same = lane > 0u && qm == pm;
-        if (rx != none && !(same && qx == px)) cc_union(parent, r, rx);
-        if (ry != none && !(same && qy == py)) cc_union(parent, r, ry);
-        if (rz != none && !(same && qz == pz)) cc_union(parent, r, rz);
+        const bool ux = cc_leader(s_tab[w], s_key[w], lane, rx != none, pm, px);
+        const bool uy = cc_leader(s_tab[w], s_key[w], lane, ry != none, pm, py);
+        const bool uz = cc_leader(s_tab[w], s_key[w], lane, rz != none, pm, pz);
+        if (ux) cc_union(parent, r, rx);
+        if (uy) cc_union(parent, r, ry);
+        if (uz) cc_union(parent, r, rz);
     }
 }
 

@@ -524,6 +524,13 @@ def _match_triangle_sets(a, b, tol):
     (EQ["eq3"], 48, (0.0, 0.33, 0.0), (1.0, 1.0, 1.0)),
     (EQ["eq8"], 40, (0.0, 0.0, 0.6), (1.0, 1.0, 1.0)),
     (EQ["sphere"], 40, (0.5, 0.0, 0.0), (2.0, 1.0, 1.5)),        # seed / scale picks the cell (marching.cpp:106-108)
+    # whole layers / rows of surface cells: a 64-segment group holds thousands of records (several LDS windows of the
+    # component labelling), and the sheets are separate components
+    ("z^2-0.25", 64, (0.1, -0.2, 0.5), (1.0, 1.0, 1.0)),
+    ("y^2-0.25", 64, (0.1, -0.5, 0.3), (1.0, 1.0, 1.0)),
+    ("z^2-0.25", 150, (0.1, -0.2, -0.5), (1.0, 1.0, 1.0)),
+    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.3, 0.2, 0.0), (1.0, 1.0, 1.0)),   # a small sphere inside a large one
+    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.0, 0.0, 0.7746), (1.0, 1.0, 1.0)),
 ])
 def test_seed_mode(mc, orc, eq, n, seed, scale):
     step = step_of(n)
@@ -540,6 +547,46 @@ def test_seed_mode(mc, orc, eq, n, seed, scale):
         c.seed_mode(False)
         full = c.march(eq, step, 0.0, scale)
         assert np.array_equal(r.codes(), full.codes()) and r.n_tris <= full.n_tris
+    finally:
+        c.close()
+
+
+def _subsequence_gaps(full, part, limit=64):
+    """Indices of `full`'s rows (u32 words) missing from `part`, which must be `full` with a few rows taken out."""
+    gaps, shift, i = [], 0, 0
+    while i - shift < len(part):
+        n = min(len(full) - i, len(part) - (i - shift))
+        ne = (full[i:i + n] != part[i - shift:i - shift + n]).any(axis=1)
+        if not ne.any():
+            i += n
+            break
+        k = int(np.argmax(ne))
+        gaps.append(i + k)
+        assert len(gaps) <= limit, "too many rows missing"
+        i += k + 1
+        shift += 1
+    gaps.extend(range(i, len(full)))
+    assert len(full) - len(gaps) == len(part), "not a sub-sequence"
+    return gaps
+
+
+def test_seed_mode_headline_grid_is_the_same_component_every_time(mc):
+    """1025^3 sphere, 4.9 M records in one component, labelled by ~80 k waves racing on one union-find: the result must be
+    the dense list minus the triangles of the outermost cells (index N, marching.cpp:84-86) -- every time."""
+    step = step_of(1024)
+    c = mc.Context(0)
+    try:
+        fv = u32(c.march(EQ["sphere"], step, flags=0).vertices()[:, :, :3]).reshape(-1, 9).copy()
+        c.set_seed(1.0, 0.0, 0.0)
+        c.seed_mode(True)
+        for _ in range(3):
+            r = c.march(EQ["sphere"], step, flags=0)
+            assert r.n_tris == 9881649
+            rv = u32(r.vertices()[:, :, :3]).reshape(-1, 9)
+            gaps = _subsequence_gaps(fv, rv)
+            assert len(gaps) == 11
+            pos = fv[gaps].view(np.float32).reshape(-1, 3, 3)
+            assert (pos.max(axis=(1, 2)) >= 1.0 - 1e-6).all()     # all at the +1 faces of the domain
     finally:
         c.close()
 
