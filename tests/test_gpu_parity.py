@@ -338,6 +338,27 @@ def test_torus_512_properties(mc, ctx):
     assert np.array_equal(u32(np.concatenate([va, b.vertices()])), u32(v))
 
 
+@pytest.mark.parametrize("name,n,iso,z", [
+    ("sphere", 1024, 0.0, (511, 515)),     # the headline grid: the equator layers (longest surface rows) ...
+    ("sphere", 1024, 0.0, (1, 4)),         # ... the pole, where the surface grazes whole layers ...
+    ("sphere", 1024, 0.0, (1022, 1025)),   # ... and the last layers (tail plane, lattice end)
+    ("eq3", 512, 0.0, (255, 259)),         # BASELINE config 3
+    ("eq3", 512, 0.0, (300, 303)),
+    ("goursat", 512, -0.4, (100, 103)),    # BASELINE config 5's surface
+    ("goursat", 512, -0.7, (436, 439)),
+])
+def test_full_size_grids_thin_slabs_against_the_oracle(mc, orc, ctx, name, n, iso, z):
+    """BASELINE's full-size grids, a few layers at a time (what the CPU oracle sweeps in seconds): cube codes and the
+    soup bit for bit against the oracle in exact-power mode, and against the REFERENCE's semantics (libm powf): the
+    same cube codes, positions within 1e-5 (north star)."""
+    eq, step = EQ[name], step_of(n)
+    r, o = check_against_oracle(mc, orc, ctx, eq, step, iso=iso, z=z)
+    assert o.n_tris > 0
+    ref = orc.march(eq, step, iso, pow_mode=orc.POW_LIBM, want=orc.WANT_CODES | orc.WANT_SOUP, z_begin=z[0], z_end=z[1])
+    assert np.array_equal(r.codes(), ref.codes) and r.n_tris == ref.n_tris
+    assert np.abs(r.soup() - ref.soup).max() <= TOL_POS
+
+
 def test_sphere_1024_properties(mc, ctx):
     """The headline workload: 1025^3 cells.  Count scaling, closed-surface and on-sphere properties."""
     r = ctx.march(EQ["sphere"], step_of(1024), flags=mc.FLAG_NORMALS)

@@ -138,6 +138,28 @@ def test_interval_culling_of_trig_is_exact(mc, ext, eq, n, scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("z", [(700, 703), (0, 2), (1023, 1025)])
+def test_gyroid_1024_thin_slabs_against_the_oracle(mc, orc, ext, z):
+    """BASELINE config 4 at its full size (1025^3 cells, scale 4 pi), three layers at a time: codes, counts and positions
+    bit for bit against the oracle, normals within 1e-6; both emit kernels."""
+    n, s = 1024, 12.566371
+    step = float(f32(2.0) / f32(n))
+    c = mc.Context(0)
+    try:
+        o = orc.march(GYROID, step, 0.0, (s,) * 3, pow_mode=orc.POW_EXACT, want=7, z_begin=z[0], z_end=z[1])
+        assert o.n_tris > 50000
+        for force in (0, mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED):
+            r = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | force, z[0], z[1])
+            assert np.array_equal(r.codes(), o.codes)
+            assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+            v = r.vertices()
+            assert np.array_equal(_u32(v[:, :, :3]), _u32(o.soup))
+            assert np.nanmax(np.abs(v[:, :, 3:] - o.normals)) <= 1e-6
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_gyroid_512_slabs_and_properties(mc, ext):
     """BASELINE config 4's surface at a size the box finishes quickly: z-slabs concatenate to the whole sweep, every
     vertex lies on a cell edge and on the surface (|f| small)."""
