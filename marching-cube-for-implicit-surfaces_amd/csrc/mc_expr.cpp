@@ -320,53 +320,143 @@ CompileStatus compile(const std::string& eq, Program& out, std::string& err, uns
 }
 
 // ------------------------------------------------------------------ codegen
+namespace {
+std::string node_name(const Program& p, int id) {
+    const Node& n = p.nodes[id];
+    if (n.op == NodeOp::VARX) return "x";
+    if (n.op == NodeOp::VARY) return "y";
+    if (n.op == NodeOp::VARZ) return "z";
+    return "t" + std::to_string(id);
+}
+// `const float t<i> = ...;` for node i ("" for a variable)
+std::string node_line(const Program& p, size_t i) {
+    char buf[256];
+    const Node& n = p.nodes[i];
+    auto name = [&](int id) { return node_name(p, id); };
+    std::string rhs;
+    switch (n.op) {
+    case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: return std::string();
+    case NodeOp::CONST: {
+        uint32_t u;
+        std::memcpy(&u, &n.cval, 4);
+        std::snprintf(buf, sizeof buf, "__uint_as_float(0x%08xu) /* %.9g */", u, (double)n.cval);
+        rhs = buf;
+        break;
+    }
+    case NodeOp::ADD: rhs = name(n.a) + " + " + name(n.b); break;
+    case NodeOp::SUB: rhs = name(n.a) + " - " + name(n.b); break;
+    case NodeOp::MUL: rhs = name(n.a) + " * " + name(n.b); break;
+    case NodeOp::DIV: rhs = name(n.a) + " / " + name(n.b); break;
+    case NodeOp::NEG: rhs = "-" + name(n.a); break;
+    case NodeOp::SIN: rhs = "mc_sinf(" + name(n.a) + ")"; break;
+    case NodeOp::COS: rhs = "mc_cosf(" + name(n.a) + ")"; break;
+    case NodeOp::POW: rhs = "mc_pow_general(" + name(n.a) + ", " + name(n.b) + ")"; break;
+    case NodeOp::POWI:
+        if (n.ipow == 2) rhs = name(n.a) + " * " + name(n.a);
+        else rhs = "mc_pow_int<" + std::to_string(n.ipow) + ">(" + name(n.a) + ")";
+        break;
+    }
+    return "    const float " + name((int)i) + " = " + rhs + ";\n";
+}
+// vector instructions one evaluation of node i costs (operands not included)
+int node_cost(const Node& n) {
+    switch (n.op) {
+    case NodeOp::ADD: case NodeOp::SUB: case NodeOp::MUL: case NodeOp::NEG: return 1;
+    case NodeOp::DIV: return 10;
+    case NodeOp::POWI: return n.ipow == 2 ? 1 : 6 + 4 * (n.ipow < 0 ? -n.ipow : n.ipow) + (n.ipow < 0 ? 14 : 0);
+    case NodeOp::POW: return 300;
+    case NodeOp::SIN: case NodeOp::COS: return 22;
+    default: return 0;
+    }
+}
+}  // namespace
+
 std::string emit_hip(const Program& p, const char* fname) {
     std::string s;
-    char buf[256];
     s += "// generated from: ";
     for (char c : p.equation) s.push_back((c == '\n' || c == '\r' || c == '\\') ? ' ' : c);
     s += std::string("\n__device__ __forceinline__ float ") + fname + "(float x, float y, float z) {\n";
     s += "    (void)x; (void)y; (void)z;\n";
-    auto name = [&](int id) -> std::string {
-        const Node& n = p.nodes[id];
-        if (n.op == NodeOp::VARX) return "x";
-        if (n.op == NodeOp::VARY) return "y";
-        if (n.op == NodeOp::VARZ) return "z";
-        std::snprintf(buf, sizeof buf, "t%d", id);
-        return buf;
-    };
-    for (size_t i = 0; i < p.nodes.size(); ++i) {
-        const Node& n = p.nodes[i];
-        std::string rhs;
-        switch (n.op) {
-        case NodeOp::VARX: case NodeOp::VARY: case NodeOp::VARZ: continue;
-        case NodeOp::CONST: {
-            uint32_t u;
-            std::memcpy(&u, &n.cval, 4);
-            std::snprintf(buf, sizeof buf, "__uint_as_float(0x%08xu) /* %.9g */", u, (double)n.cval);
-            rhs = buf;
-            break;
-        }
-        case NodeOp::ADD: rhs = name(n.a) + " + " + name(n.b); break;
-        case NodeOp::SUB: rhs = name(n.a) + " - " + name(n.b); break;
-        case NodeOp::MUL: rhs = name(n.a) + " * " + name(n.b); break;
-        case NodeOp::DIV: rhs = name(n.a) + " / " + name(n.b); break;
-        case NodeOp::NEG: rhs = "-" + name(n.a); break;
-        case NodeOp::SIN: rhs = "mc_sinf(" + name(n.a) + ")"; break;
-        case NodeOp::COS: rhs = "mc_cosf(" + name(n.a) + ")"; break;
-        case NodeOp::POW: rhs = "mc_pow_general(" + name(n.a) + ", " + name(n.b) + ")"; break;
-        case NodeOp::POWI:
-            if (n.ipow == 2) rhs = name(n.a) + " * " + name(n.a);
-            else {
-                std::snprintf(buf, sizeof buf, "mc_pow_int<%d>(", n.ipow);
-                const std::string call = buf;  // name() reuses buf: copy before calling it
-                rhs = call + name(n.a) + ")";
-            }
-            break;
-        }
-        s += "    const float " + name((int)i) + " = " + rhs + ";\n";
+    for (size_t i = 0; i < p.nodes.size(); ++i) s += node_line(p, i);
+    s += "    return " + node_name(p, p.root) + ";\n}\n";
+    return s;
+}
+
+// f with its expensive ONE-VARIABLE sub-expressions taken out: `mc_f_ux(x, U)`, `mc_f_uy`, `mc_f_uz` evaluate the
+// maximal sub-expressions that depend on that variable alone and cost at least min_cost vector instructions (sin / cos,
+// divisions, higher powers), `mc_f_t(x, y, z, UX, UY, UZ)` is f from the coordinates and those values -- composed, the
+// very operations of mc_f in the same order.  On a lattice such a sub-expression has n1 + 1 distinct values per axis
+// however many samples the sweep takes, so mc_runtime tabulates them once per (equation, lattice) -- at the lattice
+// coordinates and at coordinate +- h for the normals -- and the kernels read instead of evaluating.  "" when f has
+// no such sub-expression or is one itself.  Defines MC_TAB, MC_TAB_NX / NY / NZ (sub-expressions per variable, >= 1 as
+// array sizes) and MC_TAB_HAS_X / Y / Z.
+std::string emit_hip_tabulated(const Program& p, int min_cost) {
+    const size_t n = p.nodes.size();
+    std::vector<char> used_outside(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const Node& nd = p.nodes[i];
+        const bool uni = nd.deps == 1 || nd.deps == 2 || nd.deps == 4;
+        for (int o : {nd.a, nd.b})
+            if (o >= 0 && !(uni && p.nodes[o].deps == nd.deps)) used_outside[o] = 1;  // a user that depends on more (or on less: never) than the operand
     }
-    s += "    return " + name(p.root) + ";\n}\n";
+    const Node& rt = p.nodes[p.root];
+    if (rt.deps == 0 || rt.deps == 1 || rt.deps == 2 || rt.deps == 4) return std::string();  // f of one variable: nothing to combine
+    std::vector<int> hoisted[3];
+    std::vector<char> stage[3], in;
+    for (auto& st : stage) st.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const Node& nd = p.nodes[i];
+        const int v = nd.deps == 1 ? 0 : nd.deps == 2 ? 1 : nd.deps == 4 ? 2 : -1;
+        if (v < 0 || !used_outside[i] || nd.op == NodeOp::VARX || nd.op == NodeOp::VARY || nd.op == NodeOp::VARZ) continue;
+        // cost of the node's cone (every node once)
+        in.assign(n, 0);
+        in[i] = 1;
+        int c = 0;
+        for (size_t k = i + 1; k-- > 0;) {
+            if (!in[k]) continue;
+            c += node_cost(p.nodes[k]);
+            if (p.nodes[k].a >= 0) in[p.nodes[k].a] = 1;
+            if (p.nodes[k].b >= 0) in[p.nodes[k].b] = 1;
+        }
+        if (c < min_cost) continue;
+        hoisted[v].push_back((int)i);
+        for (size_t k = 0; k < n; ++k) stage[v][k] = stage[v][k] | in[k];
+    }
+    if (hoisted[0].empty() && hoisted[1].empty() && hoisted[2].empty()) return std::string();
+    for (const auto& h : hoisted)
+        if (h.size() > 6) return std::string();
+    const char* var = "xyz";
+    const char* VAR = "XYZ";
+    std::string s = "#define MC_TAB 1\n";
+    for (int v = 0; v < 3; ++v) {
+        s += std::string("#define MC_TAB_N") + VAR[v] + " " + std::to_string(hoisted[v].empty() ? 1 : hoisted[v].size()) + "\n";
+        if (!hoisted[v].empty()) s += std::string("#define MC_TAB_HAS_") + VAR[v] + " 1\n";
+    }
+    for (int v = 0; v < 3; ++v) {
+        s += std::string("__device__ __forceinline__ void mc_f_u") + var[v] + "(float " + var[v] + ", float (&U)[MC_TAB_N" + VAR[v] + "]) {\n";
+        s += std::string("    (void)") + var[v] + "; U[0] = 0.0f;\n";
+        for (size_t i = 0; i < n; ++i)
+            if (stage[v][i]) s += node_line(p, i);
+        for (size_t k = 0; k < hoisted[v].size(); ++k) s += "    U[" + std::to_string(k) + "] = t" + std::to_string(hoisted[v][k]) + ";\n";
+        s += "}\n";
+    }
+    std::vector<char> need(n, 0), is_h(n, 0);
+    for (const auto& h : hoisted)
+        for (int i : h) is_h[i] = 1;
+    need[p.root] = 1;
+    for (size_t i = n; i-- > 0;) {
+        if (!need[i] || is_h[i]) continue;
+        if (p.nodes[i].a >= 0) need[p.nodes[i].a] = 1;
+        if (p.nodes[i].b >= 0) need[p.nodes[i].b] = 1;
+    }
+    s += "__device__ __forceinline__ float mc_f_t(float x, float y, float z, const float (&UX)[MC_TAB_NX], const float (&UY)[MC_TAB_NY], "
+         "const float (&UZ)[MC_TAB_NZ]) {\n    (void)x; (void)y; (void)z; (void)UX; (void)UY; (void)UZ;\n";
+    for (int v = 0; v < 3; ++v)
+        for (size_t k = 0; k < hoisted[v].size(); ++k)
+            s += "    const float t" + std::to_string(hoisted[v][k]) + " = U" + VAR[v] + "[" + std::to_string(k) + "];\n";
+    for (size_t i = 0; i < n; ++i)
+        if (need[i] && !is_h[i]) s += node_line(p, i);
+    s += "    return " + node_name(p, p.root) + ";\n}\n";
     return s;
 }
 
@@ -697,14 +787,7 @@ float eval_host(const Program& p, float x, float y, float z) {
 namespace mc {
 int vector_op_cost(const Program& p) {
     int cost = 0;
-    for (const Node& n : p.nodes) switch (n.op) {
-        case NodeOp::ADD: case NodeOp::SUB: case NodeOp::MUL: case NodeOp::NEG: cost += 1; break;
-        case NodeOp::DIV: cost += 10; break;
-        case NodeOp::POWI: cost += n.ipow == 2 ? 1 : 6 + 4 * (n.ipow < 0 ? -n.ipow : n.ipow) + (n.ipow < 0 ? 14 : 0); break;
-        case NodeOp::POW: cost += 300; break;
-        case NodeOp::SIN: case NodeOp::COS: cost += 22; break;
-        default: break;
-    }
+    for (const Node& n : p.nodes) cost += node_cost(n);
     return cost;
 }
 }  // namespace mc

@@ -74,6 +74,10 @@ std::string emit_hip_interval(const Program& p, const char* fname = "mc_f_iv");
 // costs at least min_cost vector instructions to bound.
 std::string emit_hip_interval_staged(const Program& p, int min_cost = 40);
 
+// f with its expensive one-variable sub-expressions taken out (see mc_expr.cpp): `#define MC_TAB`, `mc_f_ux / uy / uz`
+// (the sub-expressions of one variable) and `mc_f_t` (f from coordinates and those values); "" when there is none.
+std::string emit_hip_tabulated(const Program& p, int min_cost = 15);
+
 // Diagnostic host interpretation of the DAG (same float ops; see mc_hip.h mc_expr_debug_eval_host).
 float eval_host(const Program& p, float x, float y, float z);
 

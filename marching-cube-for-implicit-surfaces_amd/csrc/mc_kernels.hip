@@ -152,6 +152,7 @@ struct McParams {
     u64 cap_recs;       // capacity of the record buffer in records (MC_NCUR equal regions)
     const u32* overflow;  // the overflow word for the kernels BEHIND the scan (the scan moves it into the sweep's totals and
                           // clears the allocator for the next sweep)
+    const float* tab;     // MC_TAB: f's one-variable sub-expressions per lattice index (mc_tabulate), else unused
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
@@ -197,6 +198,50 @@ __device__ __forceinline__ float mc_F(const McParams& p, float x, float y, float
     return mc_f(p.sx * x, p.sy * y, p.sz * z);
 #endif
 }
+
+// ------------------------------------------------------------------ MC_TAB: tabulated one-variable sub-expressions
+// Equations with expensive sub-expressions of ONE variable (sin / cos, divisions, higher powers; mc_expr.cpp:
+// emit_hip_tabulated) come with mc_f_ux / uy / uz (those sub-expressions) and mc_f_t (f from coordinates and their
+// values).  At lattice coordinates such a sub-expression has n1 + 1 distinct values per axis, so mc_tabulate evaluates
+// them once per (equation, lattice): table (v, w, k)[i] = sub-expression k of variable v at the argument mc_F passes for
+// lattice index i -- w = 0: s_v * c[i];  w = 1: s_v * (c[i] + h);  w = 2: s_v * (c[i] - h), h = step / 2, the arguments
+// of the normal's central differences (float operations exactly as mc_F and mc_grad_normal perform them, so a table
+// value IS the value the kernels would have computed).  mc_classify's back-end and mc_emit read instead of evaluating:
+// of the 13 sin / cos argument reductions a gyroid vertex costs, 3 are left (the interpolated coordinate and its +- h).
+#ifdef MC_TAB
+#define MC_TAB_NK (MC_TAB_NX > MC_TAB_NY ? (MC_TAB_NX > MC_TAB_NZ ? MC_TAB_NX : MC_TAB_NZ) : (MC_TAB_NY > MC_TAB_NZ ? MC_TAB_NY : MC_TAB_NZ))
+__device__ __forceinline__ u32 mc_tab_stride(int n1) { return ((u32)n1 + 1u + 63u) & ~63u; }
+// table of sub-expression k of variable v, argument kind w
+__device__ __forceinline__ const float* mc_tab_ptr(const float* tab, u32 stride, int v, int w, int k) {
+    return tab + (u32)((v * 3 + w) * MC_TAB_NK + k) * stride;
+}
+extern "C" __global__ __launch_bounds__(256) void mc_tabulate(const McParams* __restrict__ P, float* __restrict__ tab) {
+    const McParams p = *P;
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i > p.n1) return;
+    const u32 stride = mc_tab_stride(p.n1);
+    const float c = p.axis[i], h = 0.5f * p.step;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float cc = w == 0 ? c : w == 1 ? c + h : c - h;
+#ifdef MC_UNIT_SCALE
+        const float ax = cc, ay = cc, az = cc;
+#else
+        const float ax = p.sx * cc, ay = p.sy * cc, az = p.sz * cc;
+#endif
+        float UX[MC_TAB_NX], UY[MC_TAB_NY], UZ[MC_TAB_NZ];
+        mc_f_ux(ax, UX);
+        mc_f_uy(ay, UY);
+        mc_f_uz(az, UZ);
+#pragma unroll
+        for (int k = 0; k < MC_TAB_NX; ++k) tab[(u32)((0 * 3 + w) * MC_TAB_NK + k) * stride + (u32)i] = UX[k];
+#pragma unroll
+        for (int k = 0; k < MC_TAB_NY; ++k) tab[(u32)((1 * 3 + w) * MC_TAB_NK + k) * stride + (u32)i] = UY[k];
+#pragma unroll
+        for (int k = 0; k < MC_TAB_NZ; ++k) tab[(u32)((2 * 3 + w) * MC_TAB_NK + k) * stride + (u32)i] = UZ[k];
+    }
+}
+#endif
 
 // Wavefront (64-lane) inclusive prefix sum in 7 DPP adds: row_shr 1,2,3 / 4 / 8 inside the
 // 16-lane rows, then row_bcast15 / row_bcast31 across rows (gfx9 wave64 DPP controls).
@@ -312,6 +357,11 @@ struct McTileLds {
     const float* ys;   // [65]  scaled y of sample rows y0 .. y0+64 (clamped)
     const float* uy;   // [65]  unscaled
     float zk, zk1, uz0, uz1;
+#ifdef MC_TAB  // f's one-variable sub-expressions at those samples (mc_tabulate): [k][264] for x, [k][72] for y, planes z / z+1
+    const float* tx;
+    const float* ty;
+    float tz0[MC_TAB_NZ], tz1[MC_TAB_NZ];
+#endif
 };
 
 // Row state the walk leaves behind for the back-end, lane j = tile row j (v_writelane by the walk):
@@ -438,13 +488,31 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
 #ifdef MC_CONS
             u32 ob = 0;  // same layout: the sample is inside every enabled constraint (marching.cpp:255-280)
 #endif
+#ifdef MC_TAB
+            float UYl[MC_TAB_NY], UYu[MC_TAB_NY];
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NY; ++k) {
+                UYl[k] = tl.ty[k * 72 + jj];
+                UYu[k] = tl.ty[k * 72 + jj + 1];
+            }
+#endif
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 const float x = tl.xs[ln * 4 + c];
+#ifdef MC_TAB  // the same values mc_f would compute: its one-variable sub-expressions come from the tables
+                float UX[MC_TAB_NX];
+#pragma unroll
+                for (int k = 0; k < MC_TAB_NX; ++k) UX[k] = tl.tx[k * 264 + ln * 4 + c];
+                sb |= (mc_f_t(x, yl, zk, UX, UYl, tl.tz0) > iso ? 1u : 0u) << (4 * c + 0);
+                sb |= (mc_f_t(x, yl, zk1, UX, UYl, tl.tz1) > iso ? 1u : 0u) << (4 * c + 1);
+                sb |= (mc_f_t(x, yu, zk, UX, UYu, tl.tz0) > iso ? 1u : 0u) << (4 * c + 2);
+                sb |= (mc_f_t(x, yu, zk1, UX, UYu, tl.tz1) > iso ? 1u : 0u) << (4 * c + 3);
+#else
                 sb |= (mc_f(x, yl, zk) > iso ? 1u : 0u) << (4 * c + 0);
                 sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
                 sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
                 sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
+#endif
 #ifdef MC_CONS
                 ob |= (mc_ok(x, yl, zk) ? 1u : 0u) << (4 * c + 0);
                 ob |= (mc_ok(x, yl, zk1) ? 1u : 0u) << (4 * c + 1);
@@ -586,6 +654,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     __shared__ u32 s_tailbuf[MC_WPB_C][64];  // tail tiles: the rows' code dwords
     __shared__ u32 s_segcnt[MC_WPB_C][64];
     __shared__ float s_tab[MC_WPB_C][2 * 264 + 2 * 72];  // per wave: xs[264] ux[264] ys[72] uy[72] (table slices)
+#ifdef MC_TAB
+    __shared__ float s_tabu[MC_WPB_C][MC_TAB_NX * 264 + MC_TAB_NY * 72];  // per wave: slices of f's x and y sub-expression tables
+#endif
 #pragma unroll
     for (int i = (int)threadIdx.x; i < 256; i += 64 * MC_WPB_C)
         s_lut[i] = (unsigned short)(c_tri_count[i] | (c_amb_face[i] << 8));
@@ -674,6 +745,38 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         tl.zk1 = zk1;
         tl.uz0 = p.axis[iz];
         tl.uz1 = p.axis[iz + 1];
+#ifdef MC_TAB
+        {
+            const u32 ts = mc_tab_stride(n1);
+            float* ltx = s_tabu[w];
+            float* lty = s_tabu[w] + MC_TAB_NX * 264;
+#pragma unroll
+            for (int kk = 0; kk < MC_TAB_NX; ++kk) {
+                const float* __restrict__ t = mc_tab_ptr(p.tab, ts, 0, 0, kk);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int i = k * 64 + lane;
+                    if (i < 264) ltx[kk * 264 + i] = t[min(ch * MC_SEG + i, n1)];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < MC_TAB_NY; ++kk) {
+                const float* __restrict__ t = mc_tab_ptr(p.tab, ts, 1, 0, kk);
+                lty[kk * 72 + lane] = t[min(y0 + lane, n1)];
+                if (lane == 0) lty[kk * 72 + 64] = t[min(y0 + 64, n1)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < MC_TAB_NZ; ++kk) {
+                const float* __restrict__ t = mc_tab_ptr(p.tab, ts, 2, 0, kk);
+                // (made scalar HERE: a vector register would be waited for at its first use, in the back-end, behind every
+                // code store the walk has issued by then -- vmcnt retires in order)
+                tl.tz0[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t[iz])));
+                tl.tz1[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t[iz + 1])));
+            }
+            tl.tx = ltx;
+            tl.ty = lty;
+        }
+#endif
     }
 
     if (is_tail) {
@@ -1083,10 +1186,14 @@ __device__ __forceinline__ float mc_interp(float iso, float xs, float xe, float 
 }
 
 // n = g/|g|, g = central difference of F at the point, h = step/2.  false: zero or non-finite gradient.
+__device__ __forceinline__ bool mc_unit_gradient(float gx, float gy, float gz, float& nx, float& ny, float& nz);
 __device__ __forceinline__ bool mc_grad_normal(const McParams& p, float x, float y, float z, float h, float& nx, float& ny, float& nz) {
     const float gx = mc_F(p, x + h, y, z) - mc_F(p, x - h, y, z);
     const float gy = mc_F(p, x, y + h, z) - mc_F(p, x, y - h, z);
     const float gz = mc_F(p, x, y, z + h) - mc_F(p, x, y, z - h);
+    return mc_unit_gradient(gx, gy, gz, nx, ny, nz);
+}
+__device__ __forceinline__ bool mc_unit_gradient(float gx, float gy, float gz, float& nx, float& ny, float& nz) {
     const float len2 = (gx * gx + gy * gy) + gz * gz;
     if (len2 >= 1e-30f && !__builtin_isinf(len2)) {
         // v_rsq_f32 (1 ulp) instead of an IEEE sqrt and an IEEE divide: the normal is a tolerance quantity
@@ -1107,6 +1214,111 @@ __device__ __forceinline__ bool mc_grad_normal(const McParams& p, float x, float
     }
     return false;
 }
+
+#ifdef MC_TAB
+// mc_emit's phase C for the vertices of a chunk that lie on edges along AX (compile-time: the lanes of a pass all take the
+// same path), one lane per vertex.  f's one-variable sub-expressions come from the tables wherever a coordinate is a
+// lattice coordinate -- both corners, and two of the three axes of the normal's central differences (coordinate, + h,
+// - h: table kinds 0, 1, 2); only the interpolated coordinate (and its +- h) is evaluated.  Same operations on the same
+// operands as mc_F / mc_grad_normal, so the same bits.
+template <int AX>
+__device__ __forceinline__ void mc_emit_axis(const McParams& p, const float* __restrict__ axis, const unsigned char* __restrict__ list, u32 cnt,
+                                             const unsigned short* item, const u32* recw, const u32* segrec, float* vc, float iso, float h,
+                                             bool want_normals, int lane) {
+    const u32 ts = mc_tab_stride(p.n1);
+    const float* __restrict__ tab = p.tab;
+#ifdef MC_UNIT_SCALE
+    const float sx = 1.0f, sy = 1.0f, sz = 1.0f;
+#else
+    const float sx = p.sx, sy = p.sy, sz = p.sz;
+#endif
+    for (u32 j0 = 0; j0 < cnt; j0 += 64u) {
+        const u32 j = j0 + (u32)lane;
+        if (j < cnt) {
+            const u32 i = list[j];
+            const u32 it = item[i];
+            const int e = (int)(it >> 6);
+            const u32 rw = recw[it & 63u];
+            const u32 s2 = segrec[rw & 63u];
+            const int bx = (int)(((s2 >> 22) & 7u) * (u32)MC_SEG + ((rw >> 6) & 0xFFu)) + (int)((MC_EDGE_OX >> e) & 1u);
+            const int by = (int)(s2 & 2047u) + (int)((MC_EDGE_OY >> e) & 1u);
+            const int bz = (int)((s2 >> 11) & 2047u) + (int)((MC_EDGE_OZ >> e) & 1u);
+            const int bi = AX == 0 ? bx : AX == 1 ? by : bz;
+            const float x0 = axis[bx], y0 = axis[by], z0 = axis[bz];
+            const float c0 = AX == 0 ? x0 : AX == 1 ? y0 : z0;  // the edge's lower end on its axis
+            const float c1 = axis[bi + 1];                        // ... its upper end
+            float UX[MC_TAB_NX], UY[MC_TAB_NY], UZ[MC_TAB_NZ];    // at the lower corner
+            float UX1[MC_TAB_NX], UY1[MC_TAB_NY], UZ1[MC_TAB_NZ]; // at the upper corner (differs on AX only)
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NX; ++k) {
+                UX[k] = mc_tab_ptr(tab, ts, 0, 0, k)[bx];
+                UX1[k] = AX == 0 ? mc_tab_ptr(tab, ts, 0, 0, k)[bx + 1] : UX[k];
+            }
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NY; ++k) {
+                UY[k] = mc_tab_ptr(tab, ts, 1, 0, k)[by];
+                UY1[k] = AX == 1 ? mc_tab_ptr(tab, ts, 1, 0, k)[by + 1] : UY[k];
+            }
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NZ; ++k) {
+                UZ[k] = mc_tab_ptr(tab, ts, 2, 0, k)[bz];
+                UZ1[k] = AX == 2 ? mc_tab_ptr(tab, ts, 2, 0, k)[bz + 1] : UZ[k];
+            }
+            const float x1 = AX == 0 ? c1 : x0, y1 = AX == 1 ? c1 : y0, z1 = AX == 2 ? c1 : z0;
+            const float v0 = mc_f_t(sx * x0, sy * y0, sz * z0, UX, UY, UZ), v1 = mc_f_t(sx * x1, sy * y1, sz * z1, UX1, UY1, UZ1);
+            const float pu = mc_interp(iso, c0, c1, v0, v1);  // marching.cpp:557-583 for an edge walked upwards
+            const float pd = mc_interp(iso, c1, c0, v1, v0);  // ... downwards (edges 2, 3, 6, 7)
+            const float qx = AX == 0 ? pu : x0, qy = AX == 1 ? pu : y0, qz = AX == 2 ? pu : z0;
+            float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            if (want_normals) {
+                // sub-expressions at (q, q + h, q - h) per axis: evaluated on AX, read on the two lattice axes
+                float UXp[MC_TAB_NX], UXm[MC_TAB_NX], UYp[MC_TAB_NY], UYm[MC_TAB_NY], UZp[MC_TAB_NZ], UZm[MC_TAB_NZ];
+                if (AX == 0) {
+                    mc_f_ux(sx * qx, UX);
+                    mc_f_ux(sx * (qx + h), UXp);
+                    mc_f_ux(sx * (qx - h), UXm);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MC_TAB_NX; ++k) {
+                        UXp[k] = mc_tab_ptr(tab, ts, 0, 1, k)[bx];
+                        UXm[k] = mc_tab_ptr(tab, ts, 0, 2, k)[bx];
+                    }
+                }
+                if (AX == 1) {
+                    mc_f_uy(sy * qy, UY);
+                    mc_f_uy(sy * (qy + h), UYp);
+                    mc_f_uy(sy * (qy - h), UYm);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MC_TAB_NY; ++k) {
+                        UYp[k] = mc_tab_ptr(tab, ts, 1, 1, k)[by];
+                        UYm[k] = mc_tab_ptr(tab, ts, 1, 2, k)[by];
+                    }
+                }
+                if (AX == 2) {
+                    mc_f_uz(sz * qz, UZ);
+                    mc_f_uz(sz * (qz + h), UZp);
+                    mc_f_uz(sz * (qz - h), UZm);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MC_TAB_NZ; ++k) {
+                        UZp[k] = mc_tab_ptr(tab, ts, 2, 1, k)[bz];
+                        UZm[k] = mc_tab_ptr(tab, ts, 2, 2, k)[bz];
+                    }
+                }
+                const float fx = sx * qx, fy = sy * qy, fz = sz * qz;
+                const float gx = mc_f_t(sx * (qx + h), fy, fz, UXp, UY, UZ) - mc_f_t(sx * (qx - h), fy, fz, UXm, UY, UZ);
+                const float gy = mc_f_t(fx, sy * (qy + h), fz, UX, UYp, UZ) - mc_f_t(fx, sy * (qy - h), fz, UX, UYm, UZ);
+                const float gz = mc_f_t(fx, fy, sz * (qz + h), UX, UY, UZp) - mc_f_t(fx, fy, sz * (qz - h), UX, UY, UZm);
+                if (!mc_unit_gradient(gx, gy, gz, nx, ny, nz)) nx = __builtin_nanf("");  // marker: see D
+            }
+            float4* o = (float4*)(vc + 8u * i);
+            o[0] = make_float4(qx, qy, qz, pd);
+            o[1] = make_float4(nx, ny, nz, 0.0f);
+        }
+    }
+}
+#endif
 
 // One wave = one GROUP of 64 consecutive segments; its records (= active cells, written by mc_classify) are taken in
 // CHUNKS of up to 64, lane = record, in sweep order.
@@ -1139,6 +1351,7 @@ struct McEmitK {
     int n1, nchunk, z_begin;
     u32 flags;
     float step, sx, sy, sz;
+    const float* tab;     // MC_TAB: McParams::tab
 };
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
@@ -1153,9 +1366,16 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
     __shared__ u32 s_own[MC_WPB_ES][64];    // ... S | first slot << 12
     __shared__ u32 s_list[MC_WPB_ES][320];  // triangles of the chunk: slot of corner k << 8k | (axis taken from p_down, 3 = none) << 24 + 2k
     __shared__ unsigned short s_item[MC_WPB_ES][MC_VCAP];  // vertices to compute: lane | edge << 6
+#ifdef MC_TAB
+    __shared__ unsigned char s_axl[MC_WPB_ES][3 * MC_VCAP];  // ... their indices, sorted by the axis of the edge
+#endif
     // No table in LDS, no workgroup barrier: the waves of a workgroup are independent (a workgroup is only a launch
     // container; it holds its LDS until its slowest wave is done, so it is kept small).  The case table row and the
     // lattice coordinates are read from memory where they are needed (L1 / L2 hits), always BEFORE a chunk's stores.
+    // (Two waves per group -- one running phases A-C, loads and arithmetic only, the other phase D, LDS reads and stores
+    // only, double-buffered through LDS with a barrier per chunk -- were measured SLOWER: gyroid 1.43 ms against 1.28, sphere
+    // 0.37 against 0.32.  The phases are chains of dependent latencies; what hides them is the number of independent chains
+    // per CU, and the split halves the waves that run any one phase.)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
     const u32 ngroups = (k.nseg + 63u) / 64u;
@@ -1177,6 +1397,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
     p.sx = k.sx;
     p.sy = k.sy;
     p.sz = k.sz;
+    p.n1 = k.n1;
+    p.tab = k.tab;
     const float* __restrict__ axis = k.axis;
 
     // the scan gives the group's first triangle; the prefix inside the group is a wavefront scan of the per-segment
@@ -1332,6 +1554,30 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         if (rn < nrec) rec_n = recs[rbase[lo_n] + (rn - actoff[lo_n])];
 
         // ---- C. one lane per computed vertex
+#ifdef MC_TAB
+        {
+            // the chunk's vertices by the axis of their edge, then one pass per axis (mc_emit_axis)
+            unsigned char* axl = s_axl[w];
+            u32 cn0 = 0u, cn1 = 0u, cn2 = 0u;
+            for (u32 i0 = 0; i0 < M; i0 += 64u) {
+                const u32 i = i0 + (u32)lane;
+                const bool v = i < M;
+                const int ax = v ? edge_axis((int)(item[i] >> 6)) : 3;
+                const u64 m0 = __ballot(ax == 0), m1 = __ballot(ax == 1), m2 = __ballot(ax == 2);
+                if (ax == 0) axl[cn0 + mask_rank(m0)] = (unsigned char)i;
+                if (ax == 1) axl[MC_VCAP + cn1 + mask_rank(m1)] = (unsigned char)i;
+                if (ax == 2) axl[2 * MC_VCAP + cn2 + mask_rank(m2)] = (unsigned char)i;
+                cn0 += (u32)__builtin_popcountll(m0);
+                cn1 += (u32)__builtin_popcountll(m1);
+                cn2 += (u32)__builtin_popcountll(m2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mc_emit_axis<0>(p, axis, axl, cn0, item, recw, segrec, vc, iso, h, want_normals, lane);
+            mc_emit_axis<1>(p, axis, axl + MC_VCAP, cn1, item, recw, segrec, vc, iso, h, want_normals, lane);
+            mc_emit_axis<2>(p, axis, axl + 2 * MC_VCAP, cn2, item, recw, segrec, vc, iso, h, want_normals, lane);
+        }
+#else
         for (u32 i0 = 0; i0 < M; i0 += 64u) {
             const u32 i = i0 + (u32)lane;
             if (i < M) {
@@ -1360,6 +1606,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
                 o[1] = make_float4(nx, ny, nz, 0.0f);
             }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

@@ -1,9 +1,12 @@
-"""CPU: the generated interval code (mc_expr.cpp: emit_hip_interval / emit_hip_interval_staged) compiled as HOST code.
+"""CPU: the generated device code (mc_expr.cpp: emit_hip_interval / emit_hip_interval_staged / emit_hip_tabulated) compiled as
+HOST code.
 
 The classify walk proves rows and lanes uniform from mc_f_iv without sampling them, and -- for equations with expensive
 sub-expressions of y alone (sin / cos, divisions, powers) -- from the two-stage form mc_f_iv_y + mc_f_iv_rest.  Checked here,
 on random boxes: (1) the staged form returns the same bits as the whole one; (2) every value mc_f computes at points of a
-box lies inside the enclosure (the property the culling's exactness rests on)."""
+box lies inside the enclosure (the property the culling's exactness rests on); (3) for equations with expensive
+one-variable sub-expressions (MC_TAB: the kernels read those from per-axis tables), mc_f_t composed with mc_f_ux / uy / uz
+returns the bits of mc_f."""
 import re
 import subprocess
 
@@ -63,10 +66,24 @@ int main() {
             if (!(v >= lo && v <= hi)) ++bad_encl;
         }
     }
+    long bad_tab = 0;
+    int ntab = 0;
+#ifdef MC_TAB
+    ntab = MC_TAB_NX + MC_TAB_NY + MC_TAB_NZ;
+    for (int it = 0; it < 200000; ++it) {
+        const float x = U(rng) * radius, y = U(rng) * radius, z = U(rng) * radius;
+        float UX[MC_TAB_NX], UY[MC_TAB_NY], UZ[MC_TAB_NZ];
+        mc_f_ux(x, UX);
+        mc_f_uy(y, UY);
+        mc_f_uz(z, UZ);
+        const float a = mc_f(x, y, z), b = mc_f_t(x, y, z, UX, UY, UZ);
+        if (std::memcmp(&a, &b, 4) && !(a != a && b != b)) ++bad_tab;
+    }
+#endif
 #ifdef MC_IV_NY
-    std::printf("staged %d bad_stage %ld bad_encl %ld\n", MC_IV_NY, bad_stage, bad_encl);
+    std::printf("staged %d bad_stage %ld bad_encl %ld tab %d bad_tab %ld\n", MC_IV_NY, bad_stage, bad_encl, ntab, bad_tab);
 #else
-    std::printf("staged 0 bad_stage %ld bad_encl %ld\n", bad_stage, bad_encl);
+    std::printf("staged 0 bad_stage %ld bad_encl %ld tab %d bad_tab %ld\n", bad_stage, bad_encl, ntab, bad_tab);
 #endif
     return 0;
 }
@@ -90,9 +107,12 @@ def run_host(mc, tmp_path, eq, radius):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
-    m = re.match(r"staged (\d+) bad_stage (\d+) bad_encl (\d+)", out)
+    m = re.match(r"staged (\d+) bad_stage (\d+) bad_encl (\d+) tab (\d+) bad_tab (\d+)", out)
     assert m, out
-    return tuple(int(g) for g in m.groups())
+    ny, bad_stage, bad_encl, ntab, bad_tab = (int(g) for g in m.groups())
+    assert bad_tab == 0, "mc_f_t composed with mc_f_u* differs from mc_f"
+    assert (ntab > 0) == ("#define MC_TAB 1" in gen)
+    return ny, bad_stage, bad_encl
 
 
 @pytest.fixture()
@@ -124,3 +144,21 @@ def test_gyroid_stages_sin_and_cos_of_y(mc, trig):
     assert ypart.count("mc_sin_iv(yl, yh") == 1 and ypart.count("mc_cos_iv(yl, yh") == 1
     rest = src[src.index("void mc_f_iv_rest("):]
     assert "yl" not in rest.split("{", 1)[1].replace("(void)yl; (void)yh;", "")   # the rest reads y only through Y[]
+
+
+TABULATED = [GYROID, "sin(3y)*x+z*z-0.2", "x^2+z^2-1/((y*y+1.5)^3)", "x*y^5+z^2-0.3", "sin(x)*sin(y)*sin(z)+sin(x)*cos(y)*cos(z)",
+             "x/(y+3)+y^4*z-0.1", "cos(2x)+cos(2y)*x-z", "sin(x+1)^2*y+cos(z)/(z*z+2)"]
+NOT_TABULATED = ["x^2+y^2+z^2-1", "x*y+z", "sin(x*y)+z", "sin(x)+0.5", "(x^2+y^2+z^2+0.1)^2-x*y"]
+
+
+@pytest.mark.parametrize("eq", TABULATED)
+def test_tabulated_form_is_mc_f(mc, trig, tmp_path, eq):
+    src = mc.expr_dump(eq)
+    assert "#define MC_TAB 1" in src and "float mc_f_t(" in src
+    run_host(mc, tmp_path, eq, 2.0)          # asserts bit equality of mc_f_t o (mc_f_ux, mc_f_uy, mc_f_uz) with mc_f
+
+
+@pytest.mark.parametrize("eq", NOT_TABULATED)
+def test_cheap_or_mixed_sub_expressions_are_not_tabulated(mc, trig, eq):
+    """x^2, x*y and the like stay in mc_f; so do functions of several variables (sin(x*y)) and f of one variable."""
+    assert "MC_TAB" not in mc.expr_dump(eq)
