@@ -172,6 +172,15 @@ struct McParams {
 #define MC_WPB_ES 1  // mc_emit: its waves are independent (no table in LDS, no barrier); a workgroup keeps its LDS until its
                      // slowest wave is done, so one wave per workgroup wastes none
 #endif
+// Cache policy of the stores that write PROVEN code rows (buffer-store aux bits: 1 = sc0, 2 = nt, 16 = sc1): ~1 GB per
+// 1025^3 sweep that nothing reads again.  Marked non-temporal they leave the write path a little sooner (classify of the
+// 1025^3 sphere, three runs each in one session: 0.235-0.241 ms with 0, 0.228-0.231 with nt, the same with sc0 | nt but the
+// emit kernel behind it 2 % slower; equation_3 at 1025^3: 0.237 -> 0.217).  NOT for the undecided rows: those are stored
+// whole and their listed dwords written over them a moment later, which only works while the line sits in L2 (with nt
+// there: 0.32 ms); nor for the emit kernels' vertex stores (two pieces per 24-byte vertex that L2 merges: 0.25 -> 0.32 ms).
+#ifndef MC_CULLED_STORE_AUX
+#define MC_CULLED_STORE_AUX 2
+#endif
 #ifndef MC_LIST_CAP
 // triangles staged per wave in the emit kernel: one chunk of 64 records holds at most 64 * 5.  The kernel
 // is latency-bound, so LDS is kept small for occupancy (measured: 0.274 ms at 768, 0.269 at 384, 0.256 at 320)
@@ -919,7 +928,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // 0.14 ms at 1025^3 (measured: every one is a read-modify-write of a cold line).
     const int rowbytes = (int)p.pitch;
     auto store_codes = [&](u32 v) {
-        __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, rowbytes, 0x00020000), xoff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, rowbytes, 0x00020000), xoff, 0, MC_CULLED_STORE_AUX);
         rowbase += p.pitch;
     };
 #if defined(MC_HAVE_IV) && defined(MC_FINITE) && !defined(MC_NO_CULL)
@@ -973,7 +982,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             v.z = c & vm4[2];
             v.w = c & vm4[3];
             __builtin_amdgcn_raw_buffer_store_b128(
-                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, 0);
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, MC_CULLED_STORE_AUX);
         }
         // (2) the other culled rows
         u64 m1 = cull & ~blockRows;
@@ -982,7 +991,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             m1 &= m1 - 1ull;
             const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
             __builtin_amdgcn_raw_buffer_store_b32(
-                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, 0);
+                v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, MC_CULLED_STORE_AUX);
         }
         // (3) undecided rows: the lane-level masks go to lane j of rm, the row itself to the back-end.
         // Two adjacent undecided rows share ONE evaluation over the box of both (3 sample rows): half
