@@ -1,0 +1,71 @@
+// Developer micro-benchmark: how fast can MI355X WRITE 1 GiB?  Store width x cache policy x workgroup shape.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_fill.hip -o gpurun_out/ubench_fill && gpurun_out/ubench_fill
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int AUX, int WIDE>
+__global__ __launch_bounds__(256) void fill(unsigned char* p, size_t bytes_per_block, int iters) {
+    unsigned char* base = p + (size_t)blockIdx.x * bytes_per_block;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes_per_block, 0x00020000);
+    for (int i = 0; i < iters; ++i) {
+        if (WIDE) {
+            u32x4 v = {1u, 2u, 3u, (u32)i};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, (u32)(i * 4096 + threadIdx.x * 16), 0, AUX);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32((u32)i, r, (u32)(i * 1024 + threadIdx.x * 4), 0, AUX);
+        }
+    }
+}
+
+template <int AUX, int WIDE>
+int run(unsigned char* d, size_t total, int iters, const char* name) {
+    const size_t per_block = (size_t)iters * (WIDE ? 4096 : 1024);
+    const unsigned blocks = (unsigned)(total / per_block);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL((fill<AUX, WIDE>), dim3(blocks), dim3(256), 0, 0, d, per_block, iters);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-28s iters %3d  %8.4f ms  %7.1f GB/s\n", name, iters, best, (double)blocks * per_block / best / 1e6);
+    return 0;
+}
+
+int main() {
+    const size_t total = (size_t)1 << 30;
+    unsigned char* d;
+    CHECK(hipMalloc(&d, total));
+    CHECK(hipMemset(d, 0, total));
+    for (int iters : {4, 16, 64}) {
+        run<0, 1>(d, total, iters, "b128 aux0");
+        run<1, 1>(d, total, iters, "b128 sc0");
+        run<2, 1>(d, total, iters, "b128 nt");
+        run<3, 1>(d, total, iters, "b128 sc0|nt");
+        run<16, 1>(d, total, iters, "b128 sc1");
+        run<18, 1>(d, total, iters, "b128 sc1|nt");
+        run<0, 0>(d, total, iters, "b32  aux0");
+        run<2, 0>(d, total, iters, "b32  nt");
+    }
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    CHECK(hipEventRecord(a));
+    CHECK(hipMemsetAsync(d, 1, total, 0));
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    printf("hipMemsetAsync               %8.4f ms  %7.1f GB/s\n", ms, total / ms / 1e6);
+    return 0;
+}
