@@ -323,7 +323,7 @@ public:
         reset_all_data();
         error_.clear();
         if (!evaluator_) return false;
-        const bool indexed = indexed_ && !seed_mode_;  // seed mode hands over soup (its walk is not the sweep's order)
+        const bool indexed = indexed_ && !seed_mode_;  // seed mode hands over soup (the reference numbers its vertices in visitation order)
         mc_params p{};
         p.equation = evaluator_->equation().c_str();
         p.step = grid_step_size_;
