@@ -138,6 +138,34 @@ def test_interval_culling_of_trig_is_exact(mc, ext, eq, n, scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,scale,cons", [
+    (GYROID, 64, (6.2831853,) * 3, [("x", ">", -0.5)]),
+    (GYROID, 80, (12.566371, 6.2831853, 9.0), [("x+y", "<=", 0.4), ("z^2", "<", 0.6)]),
+    ("sin(3y)*x+z*z-0.2", 48, (1.0, 1.0, 1.0), [("sin(2x)", ">=", -0.3)]),       # a tabulated f under a tabulated constraint
+    ("x*y^5+z^2-0.3", 64, (1.0, 1.3, 1.0), [("1/(x*x+0.5)", "<", 1.7)]),
+])
+def test_tabulated_equations_with_constraints_and_scales(mc, orc, ext, eq, n, scale, cons):
+    """Equations whose one-variable sub-expressions come from tables (MC_TAB), with constraints (marching.cpp:476: their
+    left-hand sides are evaluated the ordinary way) and anisotropic scales: codes and soup bit for bit, either emit kernel."""
+    step = float(f32(2.0) / f32(n))
+    c = mc.Context(0)
+    try:
+        for i, (lhs, op, rhs) in enumerate(cons):
+            c.set_constraint(i, lhs, op, rhs)
+        o = orc.march(eq, step, 0.1, scale, pow_mode=orc.POW_EXACT, want=7, constraints=cons)
+        assert o.n_tris > 0
+        for force in (0, mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED):
+            r = c.march(eq, step, 0.1, scale, mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | force)
+            assert np.array_equal(r.codes(), o.codes) and (r.n_tris, r.n_active) == (o.n_tris, o.n_active)
+            v = r.vertices()
+            same = (_u32(v[:, :, :3]) == _u32(o.soup)) | (np.isnan(v[:, :, :3]) & np.isnan(o.soup))
+            assert same.all()
+            assert np.nanmax(np.abs(v[:, :, 3:] - o.normals)) <= 1e-6
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("z", [(700, 703), (0, 2), (1023, 1025)])
 def test_gyroid_1024_thin_slabs_against_the_oracle(mc, orc, ext, z):
     """BASELINE config 4 at its full size (1025^3 cells, scale 4 pi), three layers at a time: codes, counts and positions
