@@ -138,22 +138,41 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     eq = "(x^2)^2+(y^2)^2+(z^2)^2-(x^2+y^2+z^2)"
     n = 512 if args.grid_res == 1024 else args.grid_res
     step = float(np.float32(2.0) / np.float32(n))
-    ctx = mc_amd.Context(local_rank)
+    depth = max(1, args.in_flight)
+    ctxs = [mc_amd.Context(local_rank) for _ in range(depth)]
+    ctx = ctxs[0]
     frames = max(args.steps, 2)
     isos = np.linspace(-0.7, -0.1, frames).astype(np.float32)
-    ctx.graph_build(eq, step, iso=-0.4)            # -0.4 has the most triangles: sizes the vertex buffer
-    for iso in isos[: args.warmup]:
-        ctx.graph_replay(float(iso))
+    for c in ctxs:                                 # -0.4 has the most triangles: sizes the vertex buffers
+        c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING)
+
+    def play(frame_isos):
+        """Frame k goes to context k % depth (its own buffers and stream), so `depth` frames are in flight; EVERY frame's
+        triangle count is read back -- when its context comes up again, depth - 1 frames later."""
+        total, busy = 0, [False] * depth
+        for k, iso in enumerate(frame_isos):
+            c = ctxs[k % depth]
+            if busy[k % depth]:
+                total += c.graph_wait().n_tris
+            c.graph_replay_async(float(iso))
+            busy[k % depth] = True
+        for j in range(depth):
+            if busy[j]:
+                total += ctxs[j].graph_wait().n_tris
+        return total
+
+    play(isos[: args.warmup])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tris = 0
+    tris = play(isos)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # per-kernel times: the same frames once more, one at a time, from a capture that carries the hipEvent nodes
+    ctx.graph_build(eq, step, iso=-0.4)
     kt = np.zeros(4)
     for iso in isos:
         r = ctx.graph_replay(float(iso))
-        tris += r.n_tris
         kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     kt /= frames
     n1 = mc_amd.cells_per_axis(step)
     cells = float(n1) ** 3
@@ -161,12 +180,14 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     print(json.dumps({"metric": "Mtris/s", "value": round(tris / dt / 1e6, 2), "unit": "Mtris/s", "n_gpus": 1, "steps": frames,
                       "warmup": args.warmup, "ms_per_step": round(dt / frames * 1e3, 4), "higher_is_better": True,
                       "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": f"iso sweep -0.7..-0.1 on {eq}, grid_res {n} ({n1}^3 cells), one hipGraph replay per frame "
-                                             "(each frame's triangle count is read back: the host round trip is inside the time)",
-                                 "frames": frames, "triangles_total": int(tris)},
+                      "config": {"workload": f"iso sweep -0.7..-0.1 on {eq}, grid_res {n} ({n1}^3 cells), one hipGraph replay per frame, "
+                                             f"{depth} frame(s) in flight (one context = one set of buffers each); every frame's "
+                                             "triangle count is read back inside the timed region",
+                                 "frames": frames, "triangles_total": int(tris), "in_flight": depth},
                       "mvoxels_per_s": round(n1 ** 3 * frames / dt / 1e6, 1),
                       "kernel_ms": {"classify": round(kt[0], 4), "scan": round(kt[1], 4), "emit": round(kt[2], 4), "gpu_total": round(kt[3], 4),
-                                    "emit_kernel": "mc_emit" if r.emit_shared else "mc_emit_direct"},
+                                    "emit_kernel": "mc_emit" if r.emit_shared else "mc_emit_direct",
+                                    "source": "HIP events of the same frames replayed one at a time behind the timed region"},
                       "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cells / (kt[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(cells / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "traffic": pmc_traffic("mc_classify", "goursat512" if n == 512 else None),
@@ -175,7 +196,8 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
                                    "algorithmic_bytes_per_launch": int(2 * cells + 72 * tpf),
                                    "achieved": round((2 * cells + 72 * tpf) / (kt[3] * 1e-3) / 1e9, 1),
                                    "frac": round((2 * cells + 72 * tpf) / (kt[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 def main():
@@ -201,6 +223,10 @@ def main():
                          "work of an N-GPU run, to see the fixed per-step costs that bound strong scaling")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every sweep kernel by kernel (mc_march) instead of replaying the captured hipGraph (mc_graph_replay)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent sweeps kept in flight: step k runs on context k %% D (its own buffers, stream and captured "
+                         "graph), so the ramp, tail and scan bubble of one sweep are filled by its neighbours.  1: one context, "
+                         "every sweep behind the previous one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-normals", action="store_true")
     ap.add_argument("--mode", choices=["sweep", "isosweep"], default="sweep",
@@ -272,46 +298,62 @@ def main():
     # scan kernel's own store) is captured once as a hipGraph and replayed per step WITHOUT a host round trip:
     # K replays are enqueued back to back and the counts are read once at the end.  Two captures: a plain one for the
     # timed region, one with the per-kernel hipEvent nodes for the kernel times the roofline uses.
-    r0 = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)   # sizes every buffer; this rank's counts
-    if not args.no_graph:
-        ctx.graph_build(eq, step, 0.0, scale, flags | mc_amd.FLAG_NO_TIMING, zb, ze)
+    # The steps are independent sweeps; step k runs on context k % depth -- each context has its own buffers, stream and
+    # captured graph -- so `depth` sweeps are in flight and fill each other's ramps, tails and scan bubbles (one context:
+    # 0.494 ms per 1025^3 sweep; three: 0.42; on a 1/8 slab 0.088 -> 0.061: tools/concurrent_probe2.py).
+    depth = 1 if args.no_graph else max(1, args.in_flight)
+    ctxs = [ctx] + [mc_amd.Context(local_rank) for _ in range(depth - 1)]
+    r0 = None
+    for c in ctxs:
+        r0c = c.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)   # sizes every buffer; this rank's counts
+        r0 = r0 or r0c
+        if not args.no_graph:
+            c.graph_build(eq, step, 0.0, scale, flags | mc_amd.FLAG_NO_TIMING, zb, ze)
 
     # N > 1, the path's one real exchange -- per-rank triangle counts -> global offsets -- without the host in the loop:
     # the sweep leaves its counts in device memory (mc_result.d_totals); a side stream, ordered behind the sweep, copies
     # them into this step's slot and feeds the RCCL all-gather; the next sweep is ordered behind that copy (its scan
     # clears the counts).  Only the fence at the end of the timed region waits for anything.
-    lib_stream = side = totals_dev = slots = None
+    lib_streams = sides = totals_devs = slots = None
     if multi and cdev == "cuda" and not args.no_graph:
-        class _Raw:   # zero-copy view of the library's {n_tris, n_active} words
-            __cuda_array_interface__ = {"shape": (2,), "typestr": "<i8", "data": (int(r0.d_totals), False), "version": 2}
-        totals_dev = torch.as_tensor(_Raw(), device=f"cuda:{local_rank}")
-        lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
-        side = torch.cuda.Stream(device=f"cuda:{local_rank}")
+        def raw_totals(c):   # zero-copy view of a context's {n_tris, n_active} words (same address sweep after sweep)
+            class _Raw:
+                __cuda_array_interface__ = {"shape": (2,), "typestr": "<i8", "data": (int(c.graph_replay(0.0).d_totals), False), "version": 2}
+            return torch.as_tensor(_Raw(), device=f"cuda:{local_rank}")
+        totals_devs = [raw_totals(c) for c in ctxs]
+        lib_streams = [torch.cuda.ExternalStream(c.stream(), device=f"cuda:{local_rank}") for c in ctxs]
+        sides = [torch.cuda.Stream(device=f"cuda:{local_rank}") for _ in ctxs]
         slots = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int64, device=cdev)
     step_no = [0]
 
     def one_step():
+        i = step_no[0]
+        step_no[0] += 1
+        c = ctxs[i % depth]
         if args.no_graph:
-            r = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+            r = c.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
         else:
             r = None
-            ctx.graph_replay_async(0.0)
+            c.graph_replay_async(0.0)
         if multi:
-            i = step_no[0]
-            step_no[0] += 1
-            if totals_dev is not None:
+            if totals_devs is not None:
+                lib_stream, side, totals_dev = lib_streams[i % depth], sides[i % depth], totals_devs[i % depth]
                 side.wait_stream(lib_stream)
                 with torch.cuda.stream(side):
                     slots[i:i + 1].copy_(totals_dev[0:1], non_blocking=True)
                     pending.append(dist.all_gather_into_tensor(counts_dev, slots[i:i + 1], async_op=True))
                 lib_stream.wait_stream(side)
             else:   # gloo rehearsal / --no-graph: through the host
-                n_tris = r.n_tris if r is not None else ctx.graph_wait().n_tris
+                n_tris = r.n_tris if r is not None else c.graph_wait().n_tris
                 pending.append(dist.all_gather_into_tensor(counts_dev, torch.tensor([n_tris], dtype=torch.int64, device=cdev), async_op=True))
         return r
 
     def fence():
-        r = None if args.no_graph else ctx.graph_wait()
+        r = None
+        if not args.no_graph:
+            for c in ctxs:
+                rc = c.graph_wait()
+                r = r or rc
         for wk in pending:
             wk.wait()
         pending.clear()
@@ -335,6 +377,17 @@ def main():
     rf = fence()
     elapsed = time.perf_counter() - t0
     r = rf if rf is not None else r
+
+    # the same K steps with ONE sweep in flight (context 0 alone, each sweep behind the previous one), for comparison
+    serial_ms = None
+    if not multi and not args.no_graph and depth > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.graph_replay_async(0.0)
+        ctx.graph_wait()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # per-kernel GPU times for the roofline: the same K sweeps again, replayed one by one from a capture that carries the
     # hipEvent nodes (events are read on the host, so these replays are synchronous; right behind the timed region, same
@@ -387,8 +440,12 @@ def main():
                                    f"({n1}^3 cells), iso 0, scale {scale[0]:g}, normals {'off' if args.no_normals else 'on'}",
                        "cells": int(cells), "triangles": int(tris),
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
-                       "launch": "kernel by kernel" if args.no_graph else "hipGraph replays enqueued back to back, counts read once",
-                       "count_exchange": (None if not multi else "rccl all_gather_into_tensor, device-side counts" if totals_dev is not None
+                       "launch": ("kernel by kernel" if args.no_graph else
+                                  f"hipGraph replays enqueued back to back, step k on context k % {depth} ({depth} independent sweeps "
+                                  "in flight, each with its own buffers and stream), counts read once"),
+                       "in_flight": depth,
+                       "ms_per_step_one_in_flight": round(serial_ms, 4) if serial_ms is not None else None,
+                       "count_exchange": (None if not multi else "rccl all_gather_into_tensor, device-side counts" if totals_devs is not None
                                           else "all_gather_into_tensor through the host"),
                        "z_bounds": bounds if world > 1 else None},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
@@ -421,7 +478,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eq, step, n1)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,7 +4,9 @@
     python tools/profile_round.py [--tag r02] [--workloads sphere1024,torus512,gyroid1024,goursat512]
 
 Per workload (BASELINE.json configs 2/headline, 3, 4, 5):
-  1. rocprofv3 --kernel-trace --stats of the bench command                 -> <tag>_kernel_stats_<workload>.csv
+  1. rocprofv3 --kernel-trace --stats of the bench command, with one sweep in flight (kernels alone: the durations the
+     roofline uses) -> <tag>_kernel_stats_<workload>.csv, and as it runs by default (three in flight, kernels of
+     consecutive sweeps overlap) -> <tag>_kernel_stats_<workload>_inflight3.csv
   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes       -> <tag>_pmc_traffic_<workload>.json
      (HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE counts 64-byte requests as 32 on
      gfx950, see MI355X_MICROARCH.md, HBM / rocprofv3 section)
@@ -60,13 +62,17 @@ for w in wl:
     # 1. kernel trace
     d = os.path.join(out, f"stats_{w}")
     shutil.rmtree(d, ignore_errors=True)
-    run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "run", "--output-format", "csv", "--", *bench, *steps, *nocpu], 400)
-    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
-        keep(f, f"{tag}_kernel_stats_{w}.csv")
-        print(open(f).read(), flush=True)
-    # 2. traffic, one counter per pass
+    # (a) with ONE sweep in flight: the kernels run alone, their durations are what the bench line's roofline uses;
+    # (b) the default command (three sweeps in flight: consecutive sweeps overlap, so single launches take longer)
+    for suffix, more in (("", ["--in-flight", "1"]), ("_inflight3", [])):
+        shutil.rmtree(d, ignore_errors=True)
+        run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "run", "--output-format", "csv", "--", *bench, *steps, *nocpu, *more], 400)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            keep(f, f"{tag}_kernel_stats_{w}{suffix}.csv")
+            print(open(f).read(), flush=True)
+    # 2. traffic, one counter per pass (one sweep in flight: per-launch counts do not depend on it, attribution is cleaner)
     pm = {}
-    barg = "|".join(extra)
+    barg = "|".join([*extra, "--in-flight", "1"])
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         j = os.path.join(out, f"pmc_{w}_{c}.json")
         cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc.py"), j]

@@ -8,6 +8,7 @@ for n in 8 4 2 1; do
   python - "$n" <<'PY'
 import json, sys
 d = json.load(open('/tmp/slab.json'))
-print("slab_of", sys.argv[1], "ms_per_step", d["ms_per_step"], d["kernel_ms"])
+c = d["config"]
+print("slab_of", sys.argv[1], "ms_per_step", d["ms_per_step"], f"({c['in_flight']} sweeps in flight; with one in flight: {c['ms_per_step_one_in_flight']})", d["kernel_ms"])
 PY
 done
