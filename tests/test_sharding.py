@@ -137,3 +137,25 @@ def test_rebalance_layers_equalises_a_known_cost_profile():
     # degenerate inputs: nothing to balance, or fewer layers than ranks
     assert mc_amd.rebalance_layers([0, 5, 10], [0.0, 0.0]) == [0, 5, 10]
     assert mc_amd.rebalance_layers([0, 1, 2, 3], [5.0, 1.0, 1.0]) == [0, 1, 2, 3]
+
+
+@pytest.mark.gpu
+def test_bench_in_flight_sweeps_produce_the_same_counts():
+    """bench.py keeps several independent sweeps in flight (step k on context k % D).  Every frame of the iso sweep must
+    still be produced and counted: the total over the frames is the same with 1, 2 and 3 frames in flight; and the
+    headline mode reports the same triangles."""
+    totals, tris = set(), set()
+    for d in ("1", "2", "3"):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--mode", "isosweep", "--grid-res", "128", "--steps", "13", "--warmup", "2",
+                            "--in-flight", d], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["config"]["in_flight"] == int(d) and j["config"]["frames"] == 13
+        totals.add(j["config"]["triangles_total"])
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--grid-res", "192", "--steps", "7", "--warmup", "2", "--in-flight", d,
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["config"]["in_flight"] == int(d)
+        tris.add(j["config"]["triangles"])
+    assert len(totals) == 1 and len(tris) == 1
