@@ -21,6 +21,56 @@ __global__ __launch_bounds__(256) void fill(unsigned char* p, size_t bytes_per_b
     }
 }
 
+// mc_classify's store pattern without its arithmetic: a workgroup of 4 waves = the 4 x-chunks (256 B each) of a block of 63
+// rows of 1024 B; a wave writes its 256-byte column 4 rows per dwordx4 store (lane 4k+s: the 16 bytes of lanes 4k..4k+3 in
+// row j+s) -- or row by row with dword stores.
+template <int AUX, int BLOCKS4>
+__global__ __launch_bounds__(256) void tile_pattern(unsigned char* p, int rows_total) {
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int y0 = blockIdx.x * 63;
+    const int ny = min(63, rows_total - y0);
+    unsigned char* tilebase = p + (size_t)y0 * 1024;
+    const int q = lane & 3, k4 = lane & ~3;
+    if (BLOCKS4) {
+        int j = 0;
+        for (; j + 4 <= ny; j += 4) {
+            u32x4 v = {1u, 2u, 3u, (u32)j};
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(tilebase + (size_t)j * 1024, 0, 4096, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, (u32)(q * 1024 + ch * 256 + k4 * 4), 0, AUX);
+        }
+        for (; j < ny; ++j) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(tilebase + (size_t)j * 1024, 0, 1024, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32((u32)j, r, (u32)(ch * 256 + lane * 4), 0, AUX);
+        }
+    } else {
+        for (int j = 0; j < ny; ++j) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(tilebase + (size_t)j * 1024, 0, 1024, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32((u32)j, r, (u32)(ch * 256 + lane * 4), 0, AUX);
+        }
+    }
+}
+
+template <int AUX, int BLOCKS4>
+int run_pattern(unsigned char* d, size_t total, const char* name) {
+    const int rows = (int)(total / 1024);
+    const unsigned blocks = (unsigned)((rows + 62) / 63);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL((tile_pattern<AUX, BLOCKS4>), dim3(blocks), dim3(256), 0, 0, d, rows);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-44s %8.4f ms  %7.1f GB/s\n", name, best, (double)rows * 1024 / best / 1e6);
+    return 0;
+}
+
 template <int AUX, int WIDE>
 int run(unsigned char* d, size_t total, int iters, const char* name) {
     const size_t per_block = (size_t)iters * (WIDE ? 4096 : 1024);
@@ -57,6 +107,10 @@ int main() {
         run<0, 0>(d, total, iters, "b32  aux0");
         run<2, 0>(d, total, iters, "b32  nt");
     }
+    run_pattern<0, 1>(d, total, "classify tile pattern, 4-row blocks, aux0");
+    run_pattern<2, 1>(d, total, "classify tile pattern, 4-row blocks, nt");
+    run_pattern<0, 0>(d, total, "classify tile pattern, row by row, aux0");
+    run_pattern<2, 0>(d, total, "classify tile pattern, row by row, nt");
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
