@@ -469,6 +469,10 @@ def main():
             "pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(pipe_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(pipe_bytes),
                          "formula": "2*C + 72*T (SURVEY 8d)",
+                         # achieved / frac above: the kernels of ONE sweep, alone (their HIP-event times).  The same bytes over
+                         # the time a step takes in the timed region, where `in_flight` sweeps overlap:
+                         "achieved_in_flight": round(pipe_bytes / (ms_step * 1e-3) / 1e9, 1),
+                         "frac_in_flight": round(pipe_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "counter_bytes_per_launch": (t_cls + t_emit) if (t_cls is not None and t_emit is not None) else None,
                          "frac_by_counter_bytes": (round((t_cls + t_emit) / (ms_tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                    if (t_cls is not None and t_emit is not None and ms_tot > 0) else None)},
