@@ -50,6 +50,47 @@ __global__ __launch_bounds__(256) void tile_pattern(unsigned char* p, int rows_t
     }
 }
 
+// the emit kernels' store pattern: 24 bytes per lane (one vertex) as a 16-byte and an 8-byte store, 1536 contiguous bytes
+// per pair of instructions -- against the same bytes written as contiguous 16-byte pieces (what an LDS transposition in
+// front of the stores would produce: 1.5 instructions per 64 vertices)
+template <int TRANSPOSED>
+__global__ __launch_bounds__(64) void vertex_pattern(unsigned char* p, int iters) {
+    const int lane = threadIdx.x;
+    unsigned char* base = p + (size_t)blockIdx.x * iters * 1536;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, iters * 1536, 0x00020000);
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    for (int i = 0; i < iters; ++i) {
+        u32x4 a = {1u, 2u, 3u, (u32)i};
+        u32x2 b = {5u, 6u};
+        if (TRANSPOSED) {
+            __builtin_amdgcn_raw_buffer_store_b128(a, r, (u32)(i * 1536 + lane * 16), 0, 0);
+            if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(a, r, (u32)(i * 1536 + 1024 + lane * 16), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(a, r, (u32)(i * 1536 + lane * 24), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b, r, (u32)(i * 1536 + lane * 24 + 16), 0, 0);
+        }
+    }
+}
+template <int TRANSPOSED>
+int run_vertex(unsigned char* d, size_t total, int iters, const char* name) {
+    const unsigned blocks = (unsigned)(total / ((size_t)iters * 1536));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL((vertex_pattern<TRANSPOSED>), dim3(blocks), dim3(64), 0, 0, d, iters);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-44s iters %3d %8.4f ms  %7.1f GB/s\n", name, iters, best, (double)blocks * iters * 1536 / best / 1e6);
+    return 0;
+}
+
 template <int AUX, int BLOCKS4>
 int run_pattern(unsigned char* d, size_t total, const char* name) {
     const int rows = (int)(total / 1024);
@@ -106,6 +147,10 @@ int main() {
         run<18, 1>(d, total, iters, "b128 sc1|nt");
         run<0, 0>(d, total, iters, "b32  aux0");
         run<2, 0>(d, total, iters, "b32  nt");
+    }
+    for (int iters : {6, 24}) {
+        run_vertex<0>(d, total, iters, "emit vertex pattern, 16 + 8 bytes per lane");
+        run_vertex<1>(d, total, iters, "the same bytes, contiguous 16-byte pieces");
     }
     run_pattern<0, 1>(d, total, "classify tile pattern, 4-row blocks, aux0");
     run_pattern<2, 1>(d, total, "classify tile pattern, 4-row blocks, nt");
