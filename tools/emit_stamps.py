@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MC_AMD_DEV_LIB", "1")
 os.environ.setdefault("MC_JIT_PATCH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "emit_stamps.patch"))
 os.environ.setdefault("MC_JIT_CACHE", "/tmp/jc_ab")
+os.environ.setdefault("MC_EMIT_MODE", "shared")   # (a cheap f would take mc_emit_direct, which carries no stamps)
 os.makedirs(os.environ["MC_JIT_CACHE"], exist_ok=True)
 import mc_amd  # noqa: E402
 
