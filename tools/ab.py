@@ -42,7 +42,7 @@ for spec in args:
         env["MC_JIT_EXTRA"] = "\n".join(extra)
     for rep in range(1, reps + 1):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", *bench_args],
-                           capture_output=True, text=True, env=env, timeout=300)
+                           capture_output=True, text=True, env=env, timeout=120)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not lines:
             print(label, rep, "FAILED", r.stderr[-600:], flush=True)
