@@ -71,6 +71,41 @@ __global__ __launch_bounds__(64) void vertex_pattern(unsigned char* p, int iters
         }
     }
 }
+// one TRIANGLE per lane: three vertices of 24 bytes each, 72 contiguous bytes per lane, written as 3 x (16 + 8) bytes
+__global__ __launch_bounds__(64) void triangle_pattern(unsigned char* p, int iters) {
+    const int lane = threadIdx.x;
+    unsigned char* base = p + (size_t)blockIdx.x * iters * 4608;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, iters * 4608, 0x00020000);
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x4 a = {1u, 2u, 3u, (u32)i};
+            u32x2 b = {5u, (u32)k};
+            __builtin_amdgcn_raw_buffer_store_b128(a, r, (u32)(i * 4608 + lane * 72 + k * 24), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b, r, (u32)(i * 4608 + lane * 72 + k * 24 + 16), 0, 0);
+        }
+    }
+}
+int run_triangle(unsigned char* d, size_t total, int iters, const char* name) {
+    const unsigned blocks = (unsigned)(total / ((size_t)iters * 4608));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(triangle_pattern, dim3(blocks), dim3(64), 0, 0, d, iters);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-44s iters %3d %8.4f ms  %7.1f GB/s\n", name, iters, best, (double)blocks * iters * 4608 / best / 1e6);
+    return 0;
+}
+
 template <int TRANSPOSED>
 int run_vertex(unsigned char* d, size_t total, int iters, const char* name) {
     const unsigned blocks = (unsigned)(total / ((size_t)iters * 1536));
@@ -152,6 +187,8 @@ int main() {
         run_vertex<0>(d, total, iters, "emit vertex pattern, 16 + 8 bytes per lane");
         run_vertex<1>(d, total, iters, "the same bytes, contiguous 16-byte pieces");
     }
+    run_triangle(d, total, 2, "one triangle per lane, 3 x (16 + 8) bytes");
+    run_triangle(d, total, 8, "one triangle per lane, 3 x (16 + 8) bytes");
     run_pattern<0, 1>(d, total, "classify tile pattern, 4-row blocks, aux0");
     run_pattern<2, 1>(d, total, "classify tile pattern, 4-row blocks, nt");
     run_pattern<0, 0>(d, total, "classify tile pattern, row by row, aux0");
