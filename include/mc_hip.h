@@ -119,6 +119,12 @@ int mc_device_count(void);        /* gfx950 devices visible to HIP; 0 when none 
  * entry point that takes an equation or a constraint.  Returns the previous setting. */
 #define MC_EXT_TRIG 1u
 unsigned mc_set_extensions(unsigned ext);
+/* Thread-safety contract: mc_set_extensions is ONE atomic word for the whole process, read by every later call that parses
+ * an equation; it is meant to be set once at start-up.  A process whose contexts need different grammars pins each one
+ * with mc_context_set_extensions(ctx, ext) -- ext >= 0 applies to every equation / constraint this context compiles from
+ * then on, whatever the process-wide word says; ext < 0 returns the context to following it.  (The context-free helpers
+ * mc_expr_check / mc_expr_validate / mc_expr_dump / mc_jit_precompile always use the process-wide word.)  A context itself
+ * is not re-entrant, like the reference's Marching object: one thread at a time per context. */
 
 /* Evaluator::set_equation / tokenize accept-reject only (evaluator.cpp:139-237): 1 accept, 0 reject. */
 int mc_expr_check(const char *equation);
@@ -143,6 +149,7 @@ int mc_jit_precompile(const char *equation, size_t *code_size);
 /* -- context -------------------------------------------------------------- */
 int mc_context_create(int device, mc_context **out);
 void mc_context_destroy(mc_context *ctx);
+int mc_context_set_extensions(mc_context *ctx, int ext);
 
 /* Evaluator::evaluate(x,y,z) for n points (evaluator.cpp:53): xyz = n*3 host floats, out = n host floats. */
 int mc_eval_points(mc_context *ctx, const char *equation, const float *xyz, size_t n, float *out);

@@ -65,6 +65,8 @@ struct Step_Data {
 struct Poly_Data {
     std::vector<float> vertex_list;       // point xyz coordinates. size = 3*num_points
     std::vector<unsigned int> tri_list;   // triangle vertex indices, size = num_triangles*3
+    Step_Data step_data;                  // marching.h:29: one cell's evaluation; filled by Marching::step_at (the sweep
+                                          // itself never builds it: the reference fills it per cell, marching.cpp:456-595)
     std::vector<float> normal_list;       // extra: unit normal per vertex, size = 3*num_points (soup: gradient of f,
                                           // DESIGN.md N1; indexed mesh: CalculateNormal of normal.h)
 };
@@ -169,12 +171,16 @@ public:
     void set_scaling_x(float s) { scale_[0] = s; }                 // marching.cpp:240-251
     void set_scaling_y(float s) { scale_[1] = s; }
     void set_scaling_z(float s) { scale_[2] = s; }
-    // marching.h:105-113, marching.cpp:173-207.  The constraints live in the GPU context; a cell with a
-    // corner outside an enabled constraint is skipped by recalculate() (marching.cpp:476).
+    // marching.h:105-113, marching.cpp:173-207.  Constraints, seed mode and the seed belong to THIS object, as in the
+    // reference (marching.h:58-69, :130-157); the GPU context several objects may share only holds the compiled copy of
+    // whichever object swept last -- recalculate() and step_at() push this object's state first (push_state).  A cell
+    // with a corner outside an enabled constraint is skipped by recalculate() (marching.cpp:476).
     bool set_constraint(int i, const std::string& lhs, const std::string& op, float rhs) {
+        if (i < 0 || i > 2) return false;
         if (mc_set_constraint(ctx_.get(), i, lhs.c_str(), op.c_str(), rhs) != MC_OK) return false;
         cons_[i].valid = true;
         cons_[i].lhs = lhs;
+        cons_[i].ops = op;
         cons_[i].op = op == ">=" ? 0 : op == "<=" ? 1 : op == ">" ? 2 : 3;
         cons_[i].rhs = rhs;
         return true;
@@ -183,7 +189,7 @@ public:
     bool set_constraint1(const std::string& l, const std::string& o, float r) { return set_constraint(1, l, o, r); }
     bool set_constraint2(const std::string& l, const std::string& o, float r) { return set_constraint(2, l, o, r); }
     bool use_constraint(int i, bool b) {
-        if (mc_use_constraint(ctx_.get(), i, b ? 1 : 0) != MC_OK) return false;
+        if (i < 0 || i > 2) return false;
         cons_[i].in_use = b;
         return b;
     }
@@ -191,12 +197,9 @@ public:
     bool use_constraint1(bool b) { return use_constraint(1, b); }
     bool use_constraint2(bool b) { return use_constraint(2, b); }
     // marching.cpp:115-137: seed mode keeps the surface reached from the seed's cell (mc_hip.h, mc_set_seed)
-    void seed_mode(bool b) {
-        mc_seed_mode(ctx_.get(), b ? 1 : 0);
-        seed_mode_ = b;
-    }
+    void seed_mode(bool b) { seed_mode_ = b; }
     bool set_seed(float x, float y, float z) {
-        if (mc_set_seed(ctx_.get(), x, y, z) != MC_OK) return false;
+        if (!((x <= 1 && x >= -1) && (y >= -1 && y <= 1) && (z >= -1 && z <= 1))) return false;  // marching.cpp:128
         seed_[0] = x; seed_[1] = y; seed_[2] = z;
         return true;
     }
@@ -207,12 +210,19 @@ public:
     // reference's step-by-step mode shows it: f comes from the GPU (mc_eval_points), the table walk and the
     // interpolation (marching.cpp:437-446) run here.  false: bad index, no evaluator, or a GPU error.
     bool step_at(int ix, int iy, int iz, Step_Data* out) {
+        const int n1 = mc_cells_per_axis(grid_step_size_);
+        if (!out || !evaluator_ || ix < 0 || iy < 0 || iz < 0 || ix >= n1 || iy >= n1 || iz >= n1) return false;
+        if (!step_at_impl(ix, iy, iz, n1, out)) return false;
+        poly_data_.step_data = *out;  // marching.h:29: where the reference's callers read the cell's trace
+        return true;
+    }
+
+private:
+    bool step_at_impl(int ix, int iy, int iz, int n1, Step_Data* out) {
         static const uint64_t tri_row[256] = MC_TRI_ROW_INIT;
         static const uint8_t amb_face[256] = MC_AMB_FACE_INIT;
         static const uint16_t face_corner[6] = MC_FACE_CORNER_INIT;
         static const uint8_t edge_corner[12] = MC_EDGE_CORNER_INIT;
-        const int n1 = mc_cells_per_axis(grid_step_size_);
-        if (!out || !evaluator_ || ix < 0 || iy < 0 || iz < 0 || ix >= n1 || iy >= n1 || iz >= n1) return false;
         std::vector<float> c((size_t)n1 + 1);
         {
             volatile float v = -1.0f;  // marching.cpp:372-377: the loop variable is advanced by float adds
@@ -309,6 +319,20 @@ public:
         }
         return true;
     }
+
+    // This object's constraints, seed mode and seed -> the (possibly shared) GPU context.  The library ignores calls
+    // that change nothing, so this is cheap when one object sweeps repeatedly.
+    bool push_state() {
+        for (int i = 0; i < 3; ++i) {
+            const Constraint& cn = cons_[i];
+            if (cn.valid && mc_set_constraint(ctx_.get(), i, cn.lhs.c_str(), cn.ops.c_str(), cn.rhs) != MC_OK) return false;
+            if (mc_use_constraint(ctx_.get(), i, (cn.valid && cn.in_use) ? 1 : 0) != MC_OK) return false;  // marching.cpp:258
+        }
+        if (mc_set_seed(ctx_.get(), seed_[0], seed_[1], seed_[2]) != MC_OK) return false;
+        return mc_seed_mode(ctx_.get(), seed_mode_ ? 1 : 0) == MC_OK;
+    }
+
+public:
     // true (default): the reference's welded Poly_Data (marching.cpp:599-654), built on the GPU; false: triangle soup
     void set_indexed(bool b) { indexed_ = b; }
 
@@ -316,6 +340,10 @@ public:
         poly_data_.vertex_list.clear();
         poly_data_.tri_list.clear();
         poly_data_.normal_list.clear();
+        poly_data_.step_data.intersect_coord.clear();  // marching.cpp:296-298
+        poly_data_.step_data.tri_vlist.clear();
+        poly_data_.step_data.edge_list.clear();
+        poly_data_.step_data.step_i = -2;              // reset_step, marching.cpp:288-290
     }
 
     // marching.cpp:308, full-sweep branch :368-384.  false = no evaluator or a GPU/compile error.
@@ -323,6 +351,10 @@ public:
         reset_all_data();
         error_.clear();
         if (!evaluator_) return false;
+        if (!push_state()) {
+            error_ = mc_last_error();
+            return false;
+        }
         const bool indexed = indexed_ && !seed_mode_;  // seed mode hands over soup (the reference numbers its vertices in visitation order)
         mc_params p{};
         p.equation = evaluator_->equation().c_str();
@@ -456,8 +488,8 @@ public:
 private:
     struct Constraint {  // marching.h:58-69 (the GPU context holds the compiled copy)
         bool valid = false, in_use = false;
-        std::string lhs;
-        int op = 0;  // 0 '>=', 1 '<=', 2 '>', 3 '<'
+        std::string lhs, ops;
+        int op = 0;  // 0 '>=', 1 '<=', 2 '>', 3 '<' (ops: as spelled)
         float rhs = 0.0f;
     } cons_[3];
 

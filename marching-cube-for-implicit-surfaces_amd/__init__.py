@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
     "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
     "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
-    "mc_set_seed", "mc_seed_mode",
+    "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
         L.mc_use_constraint.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mc_graph_build.argtypes = [C.c_void_p, C.POINTER(McParams)]
         L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
+        L.mc_context_set_extensions.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -261,6 +262,10 @@ class Context:
 
     def use_constraint(self, i: int, use: bool):
         _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))
+
+    def set_extensions(self, ext: int):
+        """Grammar extensions of THIS context (ext >= 0), whatever the process-wide setting; ext < 0: follow it again."""
+        _check(lib().mc_context_set_extensions(self._h, ext))
 
     def eval_points(self, equation, pts) -> np.ndarray:
         """Evaluator::evaluate for many points (evaluator.cpp:53), computed on the GPU."""

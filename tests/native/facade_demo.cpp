@@ -90,6 +90,44 @@ int main(int argc, char** argv) {
                 fprintf(f, "%.9g %.9g %.9g\n", pd->normal_list[i], pd->normal_list[i + 1], pd->normal_list[i + 2]);
             fclose(f);
         }
+        if (getenv("MC_DEMO_TWO_OBJECTS")) {
+            // constraints, seed mode and the seed belong to ONE Marching object (marching.h:58-69, :130-157), also when
+            // several objects share the process-wide context of the argument-less constructors
+            Evaluator ev2;
+            if (!ev2.set_equation(eq)) return 20;
+            size_t plain = 0, cons = 0;
+            {
+                Marching m1, m2;  // both on default_context()
+                for (Marching* m : {&m1, &m2}) {
+                    m->set_evaluator(&ev2);
+                    m->set_grid_step_size(2.0f / (float)grid_res);
+                    m->set_surface_constant(iso);
+                }
+                if (!m1.set_constraint0("x", ">", -0.5f) || !m1.use_constraint0(true)) return 21;
+                if (!m2.recalculate()) return 22;  // m1's constraint must not apply here
+                plain = m2.get_poly_data()->tri_list.size() / 3;
+                if (!m1.recalculate()) return 23;
+                cons = m1.get_poly_data()->tri_list.size() / 3;
+                if (!m2.recalculate() || m2.get_poly_data()->tri_list.size() / 3 != plain) return 24;
+                m1.set_seed(0.0f, 0.0f, 1.0f);
+                m1.seed_mode(true);                // m2 stays a dense, indexed sweep
+                if (!m2.recalculate() || m2.get_poly_data()->tri_list.size() / 3 != plain) return 25;
+                if (m2.get_poly_data()->vertex_list.size() / 3 >= 3 * plain) return 26;  // welded, not soup
+                if (!m1.recalculate()) return 27;
+                // step_at honours the object's own constraint and lands in poly_data.step_data (marching.h:29)
+                Step_Data sd;
+                if (!m1.step_at(0, grid_res / 2, grid_res / 2, &sd) || !sd.tri_vlist.empty()) return 28;  // x = -1: outside x > -0.5
+                if (m1.get_poly_data()->step_data.step_i != sd.step_i || sd.step_i < 1) return 29;
+                if (!m2.step_at(0, grid_res / 2, grid_res / 2, &sd)) return 30;
+                if (m2.get_poly_data()->step_data.corner_values.size() != 8) return 31;
+            }
+            Marching m3;  // a destroyed object leaves nothing behind in the shared context
+            m3.set_evaluator(&ev2);
+            m3.set_grid_step_size(2.0f / (float)grid_res);
+            m3.set_surface_constant(iso);
+            if (!m3.recalculate() || m3.get_poly_data()->tri_list.size() / 3 != plain) return 32;
+            printf("two_objects=ok plain=%zu constrained=%zu\n", plain, cons);
+        }
         if (ply) {  // PLY round trip through the reference's on-disk format (marching.cpp:665-854)
             if (!march_maker.save_poly_to_file(ply)) return 6;
             const size_t nv = pd->vertex_list.size(), ni = pd->tri_list.size();

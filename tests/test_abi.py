@@ -49,6 +49,22 @@ def test_product_does_not_link_oracle(mc):
     assert "orc_" not in syms
 
 
+def test_only_the_c_abi_is_exported(mc):
+    """The library is built with -fvisibility=hidden: of the symbols it DEFINES, `nm -D` shows the entry points
+    include/mc_hip.h declares and nothing else -- no C++ internals (mc::tokenize, mc::compile ...), no helpers."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", str(mc.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    defined = set()
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) >= 3 and parts[1] in "TtWwVvBbDdRr":
+            defined.add(parts[2])
+    # what the toolchain itself adds to every shared object / HIP fat binary registration
+    toolchain = {"_init", "_fini", "__bss_start", "_edata", "_end", "__hip_fatbin", "__hip_gpubin_handle"}
+    ours = {s for s in defined if s not in toolchain and not s.startswith("__hip_") and not s.startswith("_ZTS") and not s.startswith("_ZTI")}
+    assert ours == set(declared_symbols()), sorted(ours ^ set(declared_symbols()))
+
+
 def test_header_is_plain_c(tmp_path):
     """include/mc_hip.h must be usable from C (the boundary is a C ABI): compile a C99 translation unit that uses every
     struct and calls every entry point's prototype, syntax only."""

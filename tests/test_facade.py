@@ -180,3 +180,15 @@ def test_facade_seed_mode(mc):
                            env=dict(os.environ, MC_DEMO_SEED=seed))
         assert r.returncode == 0, r.stdout + r.stderr
         assert f" tris={tris} " in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_objects_on_one_context_keep_their_own_state(mc):
+    """Two Marching() objects share the process-wide context; constraints, seed mode and the seed are per object as in the
+    reference (marching.h:58-69, :130-157): one object's constraint must not clip the other's sweep, its seed mode must not
+    change the other's mesh, and a destroyed object leaves nothing behind."""
+    import os
+    r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "32", "0"], capture_output=True, text=True,
+                       env=dict(os.environ, MC_DEMO_TWO_OBJECTS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "two_objects=ok plain=9548 constrained=6772" in r.stdout, r.stdout   # 6772: test_facade_constraint's oracle count

@@ -86,6 +86,35 @@ def test_indexed_without_soup_and_on_wide_grids(mc, orc, ctx):
     check_indexed(mc, orc, ctx, "x+y", step_of(256), z=(0, 3))
 
 
+def test_indexed_known_deviation_from_the_std_set_is_pinned(mc, orc, ctx):
+    """The ONE documented place where MC_FLAG_INDEXED is not the reference bit for bit (mc_hip.h): points
+    closer than 1e-6 that are not bit-identical.  `x^2+y^2-0.5` at grid_res 300 has lattice points within 1e-8 of the
+    cylinder; on layers 149..151 the reference's std::set keeps 4 such points apart that the device's closed-form rule
+    merges.  Pinned so that a change of the rule shows: which vertices, how many."""
+    eq, step, z = "x^2+y^2-0.5", step_of(300), (149, 152)
+    ref = orc.march_indexed(eq, step, 0.0, pow_mode=orc.POW_EXACT, z_begin=z[0], z_end=z[1])
+    r = ctx.march(eq, step, 0.0, flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT, z_begin=z[0], z_end=z[1])
+    v, t, _ = r.indexed()
+    assert r.n_tris == ref.n_tris
+    assert ref.n_verts - r.n_verts == 4, (ref.n_verts, r.n_verts)
+    # the replay's extra vertices are duplicates of device vertices within the reference's own tolerance
+    have = {bytes(b) for b in v.view(np.uint8).reshape(-1, 12)}
+    extra = [p for p in ref.vertices if bytes(p.view(np.uint8)) not in have]
+    for p in extra:
+        assert np.abs(v - p).max(axis=1).min() < 1e-6
+    assert len(extra) <= 4
+
+
+def test_indexed_on_an_empty_slab_is_an_empty_mesh(mc, ctx):
+    """z_begin == z_end (a rank that gets no layers from shard_layers): no error, zero vertices and triangles."""
+    r = ctx.march(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT, z_begin=5, z_end=5)
+    assert (r.n_cells, r.n_tris, r.n_verts) == (0, 0, 0)
+    v, t, n = r.indexed()
+    assert v.shape == (0, 3) and t.shape == (0, 3) and n.shape == (0, 3)
+    r = ctx.march(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)   # and the context still works
+    assert (r.n_verts, r.n_tris) == (1158, 2312) or r.n_tris > 0
+
+
 def test_indexed_sphere_256_known_answer(mc, ctx):
     """the unmodified reference welds the 256-grid sphere into 308 574 vertices / 617 180 triangles."""
     r = ctx.march(EQ["sphere"], step_of(256), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
