@@ -32,7 +32,7 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 EQ3 = "(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2"   # example_files/equation_3.txt (BASELINE config 3)
 GYROID = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)"                                   # BASELINE config 4 (grammar extension E1)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def traffic_profile(workload_key):
@@ -89,7 +89,16 @@ def cpu_baseline(eq, step, n1, budget_s=15.0):
     m = orc.march(eq, step, 0.0, pow_mode=orc.POW_LIBM, want=orc.WANT_SOUP, z_begin=mid, z_end=mid + layers,
                   nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(m.n_cells / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+    ratio = None
+    try:   # committed measurement: the port against the reference proper, one thread, on the machine of BASELINE.md's table
+        rj = json.loads((ROOT / "profiles" / "r03_cpu_port_vs_reference.json").read_text())
+        x = float(rj["sphere_port_over_reference_speed"])
+        ratio = {"port_over_reference_speed_single_thread": x,
+                 "reference_equivalent_mvoxels_per_s": round(m.n_cells / dt / 1e6 / x, 4),
+                 "source": "profiles/r03_cpu_port_vs_reference.json (tools/cpu_ratio.py: oracle port vs BASELINE.md section 2, sphere)"}
+    except Exception:
+        pass
+    return {"value": round(m.n_cells / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": cores, "kind": "port", "ratio_to_reference": ratio,
             "sample": f"oracle/mc_oracle.c (libm powf, {cores} threads) on cell layers z=[{mid},{mid + layers}) of the "
                       f"same {n1}^3-cell grid: {m.n_cells} cells, {m.n_tris} triangles in {dt:.2f} s",
             "mtris_per_s": round(m.n_tris / dt / 1e6, 5)}
@@ -146,7 +155,7 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     for c in ctxs:                                 # -0.4 has the most triangles: sizes the vertex buffers
         c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING)
 
-    def play(frame_isos):
+    def play(frame_isos, depth=depth):
         """Frame k goes to context k % depth (its own buffers and stream), so `depth` frames are in flight; EVERY frame's
         triangle count is read back -- when its context comes up again, depth - 1 frames later."""
         total, busy = 0, [False] * depth
@@ -167,6 +176,12 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     tris = play(isos)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same frames with ONE frame in flight (what an application that needs frame k before it starts k + 1 sees)
+    t1 = time.perf_counter()
+    tris1 = play(isos, 1)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t1
+    assert tris1 == tris
     # per-kernel times: the same frames once more, one at a time, from a capture that carries the hipEvent nodes
     ctx.graph_build(eq, step, iso=-0.4)
     kt = np.zeros(4)
@@ -185,13 +200,19 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
                                              "triangle count is read back inside the timed region",
                                  "frames": frames, "triangles_total": int(tris), "in_flight": depth},
                       "mvoxels_per_s": round(n1 ** 3 * frames / dt / 1e6, 1),
+                      "ms_per_step_one_in_flight": round(dt1 / frames * 1e3, 4), "mtris_per_s_one_in_flight": round(tris / dt1 / 1e6, 2),
                       "kernel_ms": {"classify": round(kt[0], 4), "scan": round(kt[1], 4), "emit": round(kt[2], 4), "gpu_total": round(kt[3], 4),
                                     "emit_kernel": "mc_emit" if r.emit_shared else "mc_emit_direct",
                                     "source": "HIP events of the same frames replayed one at a time behind the timed region"},
                       "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cells / (kt[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(cells / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "traffic": pmc_traffic("mc_classify", "goursat512" if n == 512 else None),
-                                   "algorithmic_bytes_per_launch": int(cells)},
+                                   "algorithmic_bytes_per_launch": int(cells), "avg_launch_ms": round(kt[0], 4)},
+                      "second_roofline": {"bound": "hbm", "kernel": "mc_emit" if r.emit_shared else "mc_emit_direct",
+                                          "achieved": round(72 * tpf / (kt[2] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(72 * tpf / (kt[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "traffic": pmc_traffic("mc_emit" if r.emit_shared else "mc_emit_direct", "goursat512" if n == 512 else None),
+                                          "algorithmic_bytes_per_launch": int(72 * tpf), "avg_launch_ms": round(kt[2], 4)},
                       "pipeline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "formula": "2*C + 72*T (SURVEY 8d), mean frame",
                                    "algorithmic_bytes_per_launch": int(2 * cells + 72 * tpf),
                                    "achieved": round((2 * cells + 72 * tpf) / (kt[3] * 1e-3) / 1e9, 1),
@@ -452,18 +473,11 @@ def main():
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
                           "gpu_total": round(ms_tot, 4), "emit_kernel": emit_kernel,
                           "source": f"HIP events of {args.steps} synchronous replays right behind the timed region"},
-            "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4), "traffic": t_cls,
-                         "traffic_source": (f"profiles/{PROFILE_TAG}_pmc_traffic_{wkey}.json (rocprofv3 --pmc, separate passes, per launch)"
-                                            if t_cls is not None else None),
-                         "algorithmic_bytes_per_launch": int(cls_bytes)},
-            # the emit kernel by what it must write (72 B per triangle); SURVEY 8d also books 1 B/cell of code reads to it,
-            # which the record design never performs -- that byte only appears in the pipeline figure below
-            "emit_roofline": {"bound": "hbm", "kernel": emit_kernel, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                              "algorithmic_bytes_per_launch": int(72.0 * t_launch),
-                              "achieved": round(72.0 * t_launch / (ms_emit * 1e-3) / 1e9, 1) if ms_emit > 0 else 0.0,
-                              "frac": round(72.0 * t_launch / (ms_emit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_emit > 0 else 0.0,
-                              "traffic": t_emit},
+            # `roofline` is the DOMINANT kernel's (the one with the longer HIP-event time); the other one follows as
+            # `second_roofline`.  classify: 1 B per cell written.  emit: what it must write (72 B per triangle); SURVEY 8d also
+            # books 1 B/cell of code reads to it, which the record design never performs -- that byte only appears in the
+            # pipeline figure below
+            "roofline": None, "second_roofline": None,
             # the whole chain two ways: against SURVEY 8d's algorithmic bytes (which credit 1 B/cell of code READS this design
             # never performs), and against the bytes the counters actually see
             "pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -477,6 +491,22 @@ def main():
                          "frac_by_counter_bytes": (round((t_cls + t_emit) / (ms_tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                    if (t_cls is not None and t_emit is not None and ms_tot > 0) else None)},
         }
+        r_cls = {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4), "traffic": t_cls,
+                 "traffic_source": (f"profiles/{PROFILE_TAG}_pmc_traffic_{wkey}.json (rocprofv3 --pmc, separate passes, per launch)"
+                                    if t_cls is not None else None),
+                 "algorithmic_bytes_per_launch": int(cls_bytes), "avg_launch_ms": round(ms_cls, 4)}
+        emit_gbs = 72.0 * t_launch / (ms_emit * 1e-3) / 1e9 if ms_emit > 0 else 0.0
+        r_emit = {"bound": "hbm", "kernel": emit_kernel, "achieved": round(emit_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(emit_gbs / HBM_PEAK_GBS, 4), "traffic": t_emit,
+                  "traffic_source": (f"profiles/{PROFILE_TAG}_pmc_traffic_{wkey}.json (rocprofv3 --pmc, separate passes, per launch)"
+                                     if t_emit is not None else None),
+                  "algorithmic_bytes_per_launch": int(72.0 * t_launch), "avg_launch_ms": round(ms_emit, 4)}
+        out["roofline"], out["second_roofline"] = (r_emit, r_cls) if ms_emit > ms_cls else (r_cls, r_emit)
+        if serial_ms is not None:   # ONE sweep in flight: what a single march() / recalculate() call costs (steady state)
+            out["ms_per_step_one_in_flight"] = round(serial_ms, 4)
+            out["mvoxels_per_s_one_in_flight"] = round(cells / (serial_ms * 1e-3) / 1e6, 2)
+            out["mtris_per_s_one_in_flight"] = round(tris / (serial_ms * 1e-3) / 1e6, 3)
         if halo is not None:
             out["halo"] = halo
         if world == 1 and not args.no_cpu_baseline:

@@ -48,4 +48,4 @@ for spec in args:
             print(label, rep, "FAILED", r.stderr[-600:], flush=True)
             continue
         d = json.loads(lines[-1])
-        print(f"{label:22s} rep{rep} {d['kernel_ms']} step {d['ms_per_step']} tris {d['config']['triangles']}", flush=True)
+        print(f"{label:22s} rep{rep} {d['kernel_ms']} step {d['ms_per_step']} tris {d['config'].get('triangles', d['config'].get('triangles_total'))} one-in-flight {d['config'].get('ms_per_step_one_in_flight')}", flush=True)

@@ -8,7 +8,8 @@ o = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", *args], cap
 d = json.loads([l for l in o.splitlines() if l.startswith("{")][-1])
 k = d["kernel_ms"]
 print(f"{label:34s} step {d['ms_per_step']:.4f} ms  classify {k['classify']:.4f} scan {k['scan']:.4f} emit {k['emit']:.4f} ({k['emit_kernel']})  "
-      f"tris {d['config']['triangles']}  classify frac {d['roofline']['frac']:.3f}  pipeline frac {d['pipeline']['frac']:.3f}", flush=True)
+      f"tris {d['config']['triangles']}  one-in-flight {d.get('ms_per_step_one_in_flight')}  {d['roofline']['kernel']} frac {d['roofline']['frac']:.3f}  "
+      f"{d['second_roofline']['kernel']} frac {d['second_roofline']['frac']:.3f}  pipeline frac {d['pipeline']['frac']:.3f}", flush=True)
 PY
 }
 EQ3='(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2'
