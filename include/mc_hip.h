@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 2
+#define MC_ABI_VERSION 3
 
 /* Status codes (the reference returns bool / throws std::exception without text:
  * evaluator.cpp:10-13, marching.cpp:226-238). */
@@ -58,8 +58,11 @@ enum {
     MC_FLAG_NO_TIMING = 128u,  /* no per-kernel hipEvents (ms_* stay 0): four fewer nodes per sweep   */
     MC_FLAG_EMIT_DIRECT = 256u,/* diagnostic: force the emit kernel that computes every output vertex  */
                                /* on its own (the default for cheap f) ...                             */
-    MC_FLAG_EMIT_SHARED = 512u /* ... or the one that computes each lattice-edge vertex once per chunk */
+    MC_FLAG_EMIT_SHARED = 512u,/* ... or the one that computes each lattice-edge vertex once per chunk */
                                /* of cells (the default for expensive f); the output must not change   */
+    MC_FLAG_SEAM = 1024u       /* with MC_FLAG_INDEXED on a Z slab: weld the slab as a PART OF THE WHOLE     */
+                               /* GRID, so that the slabs' vertex_list / tri_list, concatenated in slab order, */
+                               /* are the single sweep's Poly_Data bit for bit (see mc_index_rebase)          */
 };
 
 typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */
@@ -171,6 +174,20 @@ int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
  * (n_tris*3 uint32) and the area-weighted vertex normals (n_verts*3 floats); any of the three may be NULL. */
 int mc_copy_indexed(mc_context *ctx, float *vertex_list, uint32_t *tri_list, float *normals, uint64_t max_verts,
                     uint64_t max_tris);
+/* One Poly_Data across Z slabs (marching.h:26-30 for a grid swept in parts, one slab per GPU).  Without MC_FLAG_SEAM a slab
+ * is welded on its own: the vertices on the plane it shares with the slab below exist in both.  With MC_FLAG_INDEXED |
+ * MC_FLAG_SEAM the slab is welded as the single sweep would weld it: a vertex belongs to the FIRST cell of the whole grid's
+ * sweep that produces it (marching.cpp:627-643), so the vertices on a slab's lower plane belong to the slab below and are
+ * not in this slab's vertex_list; n_verts counts the slab's own vertices, and the normals of the vertices on its upper
+ * plane include the triangles of the slab above (normal.h:3-41).  No data is exchanged for this: the slab sweeps one ghost
+ * layer below and one above its own layers (f is analytic) and hands out its own part.  tri_list comes back relative to the
+ * slab's first own vertex -- index i < n_verts is the slab's i-th vertex, a vertex of the slab below reads as i - 2^32 < 0
+ * (the j-th vertex from the END of that slab's list is -j) -- and
+ *     mc_index_rebase(ctx, offset)     offset = number of vertices owned by all slabs below (the one figure the ranks
+ *                                      exchange: an all-gather of n_verts, like the triangle counts)
+ * adds `offset` to every entry (mod 2^32), after which tri_list indexes the concatenation of the slabs' vertex lists.
+ * Call it once per sweep, before mc_copy_indexed.  The whole grid in one slab: MC_FLAG_SEAM changes nothing. */
+int mc_index_rebase(mc_context *ctx, uint64_t vertex_offset);
 
 /* Constraints: Marching::set_constraint0..2(lhs, op, rhs) (Source/marching.h:105-108, marching.cpp:173-200) and
  * use_constraint0..2(bool) (marching.h:110-113, marching.cpp:202-207).  i in 0..2; op is one of ">=", "<=", ">", "<";

@@ -21,7 +21,7 @@ LIB_PATH = _HERE / ("libmc_hip_dev.so" if os.environ.get("MC_AMD_DEV_LIB") == "1
 
 MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NOMEM, MC_ERR_OVERFLOW = range(8)
 FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_INDEXED, FLAG_NO_CULL, FLAG_NO_TIMING = 1, 2, 4, 8, 32, 64, 128
-FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED = 256, 512
+FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED, FLAG_SEAM = 256, 512, 1024
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
     "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
     "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
-    "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions",
+    "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions", "mc_index_rebase",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
         L.mc_graph_build.argtypes = [C.c_void_p, C.POINTER(McParams)]
         L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
         L.mc_context_set_extensions.argtypes = [C.c_void_p, C.c_int]
+        L.mc_index_rebase.argtypes = [C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -262,6 +263,10 @@ class Context:
 
     def use_constraint(self, i: int, use: bool):
         _check(lib().mc_use_constraint(self._h, i, 1 if use else 0))
+
+    def index_rebase(self, vertex_offset: int):
+        """FLAG_INDEXED | FLAG_SEAM: add the number of vertices owned by the slabs below to the last sweep's tri_list."""
+        _check(lib().mc_index_rebase(self._h, vertex_offset))
 
     def set_extensions(self, ext: int):
         """Grammar extensions of THIS context (ext >= 0), whatever the process-wide setting; ext < 0: follow it again."""

@@ -140,7 +140,9 @@ struct McParams {
     u32 flags;          // MC_FLAG_*
     float iso, step;
     float sx, sy, sz;
-    float pad;
+    int own_z_lo;       // indexed mesh: cell layers >= own_z_lo exist when the OWNER of a vertex is looked for.  z_begin: the slab
+                        // is welded on its own; 0 (MC_FLAG_SEAM): as a part of the whole grid -- layers below the swept range are
+                        // there (their cells own the keys they share with it) although they have no record here
     u64 cap_tris;       // capacity of the vertex buffer in triangles
     u32* codes_tail;    // tail plane: one dword per (z,y) row = codes of cells main_cells..n1-1 (when tail_cells)
     int main_cells;     // cells per row held by the pitched code plane (n1 when there is no tail plane)
@@ -1943,11 +1945,22 @@ __device__ __forceinline__ int mc_snap(float iso, float c0, float c1, float v0, 
     return 0;
 }
 
-// a cell of this sweep that can hold vertices: inside the slab and -- with constraints -- not skipped (marching.cpp:476;
-// a skipped cell's code byte reads 0, and a cell that contains a crossed edge never has code 0 or 255 otherwise)
+// a cell that can hold vertices: inside the sweep's ownership range (own_z_lo .. the slab's last layer) and -- with
+// constraints -- not skipped (marching.cpp:476; a skipped cell's code byte reads 0, and a cell that contains a crossed edge
+// never has code 0 or 255 otherwise).  A cell BELOW the swept layers (MC_FLAG_SEAM: the previous slab's) has no code byte
+// here: whether a constraint skips it is evaluated at its 8 corners, as the sweep that owns it does (marching.cpp:255-280).
 __device__ __forceinline__ bool mc_cell_ok(const McParams& p, const u8* __restrict__ codes, int qx, int qy, int qz) {
-    if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.z_begin || qz >= p.z_begin + p.nz) return false;
+    if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.own_z_lo || qz >= p.z_begin + p.nz) return false;
 #ifdef MC_CONS
+    if (qz < p.z_begin) {
+        const float* __restrict__ ax = p.axs;
+        const float* __restrict__ ay = p.axs + (p.n1 + 1);
+        const float* __restrict__ az = p.axs + 2 * (p.n1 + 1);
+        bool ok = true;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) ok = ok && mc_ok(ax[qx + cx_bit(v)], ay[qy + cy_bit(v)], az[qz + cz_bit(v)]);
+        return ok;
+    }
     const u64 row = (u64)(qz - p.z_begin) * (u64)p.n1 + (u64)qy;
     const u32 c = qx < p.main_cells ? (u32)codes[row * p.pitch + (u64)qx] : (p.codes_tail[row] >> (8 * (qx - p.main_cells))) & 0xFFu;
     return c != 0u && c != 255u;
@@ -2010,7 +2023,7 @@ __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restri
 #pragma unroll
         for (int da = 0; da < 2; ++da) {
             const int n = C[a] + (da == 0 ? 1 : -1);
-            const int lo_lim = a == 2 ? p.z_begin : 0, hi_lim = a == 2 ? p.z_begin + p.nz : p.n1;
+            const int lo_lim = a == 2 ? p.own_z_lo : 0, hi_lim = a == 2 ? p.z_begin + p.nz : p.n1;
             if (n < lo_lim || n > hi_lim) continue;  // no such sample in this sweep's lattice
             const float cn = axis[n], cc = a == 0 ? cx : a == 1 ? cy : cz;
             const float fn = mc_F(p, a == 0 ? cn : cx, a == 1 ? cn : cy, a == 2 ? cn : cz);
@@ -2232,6 +2245,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                 bool corner;
                 mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe, corner);
                 u32 o = myown, vb = myvb;
+                if (qz < p.z_begin) {
+                    // MC_FLAG_SEAM: the owner is a cell of the layer below the swept range (the lower plane of the ghost layer):
+                    // it has no record here and its vertex no index; only ghost cells meet this, and their triangles are
+                    // never handed out
+                    eidx[e] = 0xFFFFFFFFu;
+                    continue;
+                }
                 if (!(qx == ix && qy == iy && qz == iz)) {
                     const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
                     o = recown[q] & 0xFFFu;

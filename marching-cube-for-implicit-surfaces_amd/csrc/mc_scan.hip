@@ -219,6 +219,47 @@ extern "C" __global__ __launch_bounds__(SCAN_BLOCK) void mc_scan_onepass(u64* __
     }
 }
 
+// MC_FLAG_SEAM: where the layers that are handed out begin and end inside the swept (ghost-extended) slab.  One wave per
+// boundary: out[3 b .. 3 b + 2] = {triangles, active cells, indexed vertices} in front of segment bound[b] in sweep order --
+// the group offsets of the scans plus the prefix inside the group (per-segment counts; for the vertices the owned-edge
+// masks of the records in front).  grpvoff / recown may be null (no indexed mesh): vertices read 0.
+extern "C" __global__ __launch_bounds__(64) void mc_bounds(const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
+                                                         const uint2* __restrict__ grpvoff, const u32* __restrict__ recown,
+                                                         u32 nseg, u32 bound0, u32 bound1, u64* __restrict__ out) {
+    const u32 s = blockIdx.x == 0u ? bound0 : bound1;
+    const u32 ngroups = (nseg + 63u) / 64u;
+    const u32 g = min(s / 64u, ngroups);       // s == nseg on a group boundary: the totals behind the last group
+    const int lane = (int)threadIdx.x;
+    const u32 seg = g * 64u + (u32)lane;
+    u64 t = 0, a = 0, v = 0;
+    if (g < ngroups && seg < s && seg < nseg) {
+        const uint2 cb = segcb[seg];
+        t = cb.x & 0xFFFFu;
+        a = cb.x >> 16;
+        if (recown)
+            for (u32 i = 0; i < (cb.x >> 16); ++i) v += (u64)__builtin_popcount(recown[cb.y + i] & 0xFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        t += __shfl_xor(t, o, 64);
+        a += __shfl_xor(a, o, 64);
+        v += __shfl_xor(v, o, 64);
+    }
+    if (lane == 0) {
+        const uint2 go = grpoff[g];
+        out[3u * blockIdx.x + 0u] = (u64)go.x + t;
+        out[3u * blockIdx.x + 1u] = (u64)go.y + a;
+        out[3u * blockIdx.x + 2u] = grpvoff ? (u64)grpvoff[g].x + v : 0ull;
+    }
+}
+
+// tri_list += delta (mod 2^32): MC_FLAG_SEAM hands out indices relative to the slab's own first vertex (a vertex owned by the
+// slab below reads as a "negative" number); mc_index_rebase adds the slab's offset in the whole grid's vertex_list
+extern "C" __global__ __launch_bounds__(256) void mc_index_add(u32* __restrict__ tlist, u64 n, u32 delta) {
+    const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
+    if (i < n) tlist[i] += delta;
+}
+
 // positions only: verts[T*3][6] -> soup[T*3][3]
 extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __restrict__ verts, float* __restrict__ soup, u64 nverts) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;

@@ -23,7 +23,7 @@ def test_header_symbols_exported(mc):
 
 
 def test_abi_version(mc):
-    assert mc.lib().mc_abi_version() == 2   # v2: indexed mesh, async replay, d_totals; the host-welding helpers of v1 are gone
+    assert mc.lib().mc_abi_version() == 3   # v3: MC_FLAG_SEAM + mc_index_rebase (one Poly_Data across Z slabs), per-context extensions
 
 
 def test_no_cpu_fallback(mc):

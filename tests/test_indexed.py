@@ -115,6 +115,86 @@ def test_indexed_on_an_empty_slab_is_an_empty_mesh(mc, ctx):
     assert (r.n_verts, r.n_tris) == (1158, 2312) or r.n_tris > 0
 
 
+def nanbits(a):
+    return a.view(np.uint32) | (np.isnan(a) * np.uint32(0x7FFFFFFF))
+
+
+def check_slabs_make_the_whole(mc, c, eq, step, bounds, iso=0.0, scale=(1.0, 1.0, 1.0), soup=False):
+    """MC_FLAG_INDEXED | MC_FLAG_SEAM on consecutive Z slabs + mc_index_rebase with the running vertex count: the
+    concatenation is the whole grid's Poly_Data (marching.h:26-30) bit for bit -- vertex_list, tri_list, CalculateNormal."""
+    base = mc.FLAG_INDEXED | (mc.FLAG_NORMALS if soup else mc.FLAG_NO_EMIT)
+    w = c.march(eq, step, iso, scale, base)
+    vw, tw, nw = w.indexed()
+    sw = w.vertices() if soup else None
+    cw = w.codes()
+    n1 = w.cells_per_axis
+    vs, ts, ns, ss, cs, off, ntri = [], [], [], [], [], 0, 0
+    for zb, ze in zip(bounds[:-1], bounds[1:]):
+        r = c.march(eq, step, iso, scale, base | mc.FLAG_SEAM, zb, ze)
+        assert (r.z_begin, r.z_end, r.n_cells) == (zb, ze, n1 * n1 * (ze - zb))
+        c.index_rebase(off)
+        v, t, n = r.indexed()
+        assert v.shape == (r.n_verts, 3) and t.shape == (r.n_tris, 3)
+        vs.append(v); ts.append(t); ns.append(n)
+        cs.append(r.codes())
+        if soup:
+            ss.append(r.vertices())
+        off += r.n_verts
+        ntri += r.n_tris
+    assert (off, ntri) == (w.n_verts, w.n_tris), (off, ntri, w.n_verts, w.n_tris)
+    assert np.array_equal(np.concatenate(vs).view(np.uint32), vw.view(np.uint32)), "vertex_list of the slabs != the whole grid's"
+    assert np.array_equal(np.concatenate(ts), tw), "tri_list of the slabs != the whole grid's"
+    assert np.array_equal(nanbits(np.concatenate(ns)), nanbits(nw)), "vertex normals of the slabs != the whole grid's"
+    assert np.array_equal(np.concatenate(cs), cw)
+    if soup:
+        assert np.array_equal(np.concatenate(ss).view(np.uint32), sw.view(np.uint32))
+    return w
+
+
+SEAM_CASES = [
+    (EQ["sphere"], 32, [0, 11, 22, 33], 0.0, 1.0, ()),
+    (EQ["sphere"], 32, [0, 16, 17, 18, 33], 0.0, 1.0, ()),                     # one-layer slabs, a cut through the equator
+    ("x+y", 16, [0, 5, 9, 17], 0.0, 1.0, ()),                                    # every vertex an exact lattice hit (corner keys)
+    ("x*y*z", 12, [0, 6, 7, 13], 0.0, 1.0, ()),                                  # lattice hits shared by up to 8 cells around a seam corner
+    ("z", 8, [0, 4, 5, 9], 0.0, 1.0, ()),                                        # the surface IS the seam plane
+    ("x^2+y^2+z^2-1", 20, [0, 7, 14, 21], 0.0, 1.1, ()),                         # UI default scale
+    ("(x-0.1)*(y-0.07)*(z-0.13)-0.0001", 4, [0, 2, 3, 5], 0.0, 1.0, ()),         # ambiguity rows (SURVEY section 4)
+    (EQ["sphere"], 24, [0, 8, 16, 25], 0.0, 1.0, (("x", ">", -0.5),)),            # a constraint: skipped cells own nothing
+    (EQ["sphere"], 24, [0, 12, 13, 25], 0.0, 1.0, (("z", ">", 0.02), ("y", "<=", 0.5))),   # ... whose border is the seam
+    ("(x^2)^2+(y^2)^2+(z^2)^2-(x^2+y^2+z^2)", 32, [0, 9, 20, 33], -0.4, 1.0, ()),
+]
+
+
+@pytest.mark.parametrize("eq,n,bounds,iso,scale,cons", SEAM_CASES)
+def test_seam_slabs_concatenate_to_the_single_sweep(mc, eq, n, bounds, iso, scale, cons):
+    c = mc.Context(0)
+    try:
+        for i, (lhs, op, rhs) in enumerate(cons):
+            c.set_constraint(i, lhs, op, rhs)
+        check_slabs_make_the_whole(mc, c, eq, step_of(n), bounds, iso, (scale,) * 3, soup=True)
+    finally:
+        c.close()
+
+
+def test_seam_on_wide_grids_and_eight_ranks(mc, ctx):
+    """A tail plane (257 cells per axis), rows wider than one segment, and the 8-way split bench.py's ranks use."""
+    bounds = [mc.shard_layers(257, 8, r)[0] for r in range(8)] + [257]
+    w = check_slabs_make_the_whole(mc, ctx, EQ["sphere"], step_of(256), bounds)
+    assert (w.n_verts, w.n_tris) == (308574, 617180)      # SURVEY.md section 4: the unmodified reference's counts
+    check_slabs_make_the_whole(mc, ctx, EQ["eq3"], step_of(300), [0, 100, 150, 151, 301])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_SEEDS", "24")) // 2))
+def test_seam_random_equations_and_cuts(mc, ctx, seed):
+    rng = random.Random(9100 + seed)
+    eq = random_equation(rng)
+    n = rng.choice([16, 24, 31])
+    n1 = mc.cells_per_axis(step_of(n))
+    cuts = sorted(rng.sample(range(1, n1), rng.randint(1, 4)))
+    scale = rng.choice([(1.0, 1.0, 1.0), (1.1, 1.1, 1.1), (0.7, 1.3, 1.0)])
+    check_slabs_make_the_whole(mc, ctx, eq, step_of(n), [0] + cuts + [n1], rng.choice([0.0, 0.1, -0.2]), scale)
+
+
 def test_indexed_sphere_256_known_answer(mc, ctx):
     """the unmodified reference welds the 256-grid sphere into 308 574 vertices / 617 180 triangles."""
     r = ctx.march(EQ["sphere"], step_of(256), flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
