@@ -216,8 +216,10 @@ int mc_cells_per_axis(float step);
  *    The captured graph belongs to the sweep mc_graph_build was given (equation, step, scale, flags, slab and the
  *    constraints in force then).  Any later call that changes what it depends on -- an mc_march with other parameters
  *    that re-targets or re-allocates a buffer, mc_set_constraint / mc_use_constraint -- makes the next replay re-capture
- *    the ORIGINAL sweep first (never another equation's kernels on this one's buffers).  Seed mode and MC_FLAG_INDEXED
- *    size their buffers from the host between kernels and are refused by mc_graph_build. */
+ *    the ORIGINAL sweep first (never another equation's kernels on this one's buffers).  MC_FLAG_INDEXED (with or without
+ *    MC_FLAG_SEAM) is captured too: its five kernels follow the sweep's in the graph, the index buffers get head room at
+ *    capture time, and a frame that outgrows them is run again by mc_graph_wait / mc_graph_replay.  Seed mode sizes its
+ *    component buffers from the host between kernels and is refused by mc_graph_build. */
 int mc_graph_build(mc_context *ctx, const mc_params *p);
 int mc_graph_replay(mc_context *ctx, float iso, mc_result *res);
 /* The same without the host round trip: enqueue one replay and return; mc_graph_wait blocks until everything enqueued

@@ -217,7 +217,7 @@ def test_indexed_sphere_1024_properties(mc, ctx):
     assert r.ms_index > 0
 
 
-def test_indexed_refused_in_seed_mode_and_graphs(mc):
+def test_indexed_refused_in_seed_mode(mc):
     c = mc.Context(0)
     try:
         c.set_seed(1.0, 0.0, 0.0)
@@ -225,12 +225,44 @@ def test_indexed_refused_in_seed_mode_and_graphs(mc):
         with pytest.raises(mc.McError) as e:
             c.march(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED)
         assert e.value.code == mc.MC_ERR_ARG
-        c.seed_mode(False)
-        with pytest.raises(mc.McError) as e:
-            c.graph_build(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED)
-        assert e.value.code == mc.MC_ERR_ARG
     finally:
         c.close()
+
+
+def test_indexed_mesh_in_a_captured_graph(mc, orc):
+    """mc_graph_build accepts MC_FLAG_INDEXED: the five indexing kernels are nodes behind the sweep's, no host round trip;
+    every replayed frame equals the un-captured sweep at that iso, also the frames that outgrow the buffers the capture
+    sized (they are run again by mc_graph_wait) and frames replayed asynchronously."""
+    eq, step = EQ["goursat"], step_of(48)
+    c, d = mc.Context(0), mc.Context(0)
+    try:
+        flags = mc.FLAG_INDEXED | mc.FLAG_NORMALS
+        c.graph_build(eq, step, iso=-0.69, flags=flags)       # few triangles: later frames outgrow these buffers
+        for iso in (-0.69, -0.4, -0.1, -0.55, -0.4):
+            r = c.graph_replay(iso)
+            w = d.march(eq, step, iso, flags=flags)
+            assert (r.n_verts, r.n_tris) == (w.n_verts, w.n_tris) and r.n_verts > 0
+            for a, b in zip(r.indexed(), w.indexed()):
+                assert np.array_equal(nanbits(a) if a.dtype == np.float32 else a, nanbits(b) if b.dtype == np.float32 else b)
+            assert np.array_equal(r.vertices().view(np.uint32), w.vertices().view(np.uint32))
+        ref = orc.march_indexed(eq, step, -0.4, pow_mode=orc.POW_EXACT)
+        assert (r.n_verts, r.n_tris) == (ref.n_verts, ref.n_tris)
+        for iso in (-0.3, -0.35, -0.45):                      # three frames in flight on one context, the last one is reported
+            c.graph_replay_async(iso)
+        r = c.graph_wait()
+        w = d.march(eq, step, -0.45, flags=flags)
+        assert (r.n_verts, r.n_tris) == (w.n_verts, w.n_tris)
+        assert np.array_equal(r.indexed()[1], w.indexed()[1])
+        # a slab welded as a part of the whole grid, captured
+        c.graph_build(EQ["sphere"], step_of(32), flags=mc.FLAG_INDEXED | mc.FLAG_SEAM | mc.FLAG_NO_EMIT, z_begin=11, z_end=22)
+        r = c.graph_replay(0.0)
+        w = d.march(EQ["sphere"], step_of(32), flags=mc.FLAG_INDEXED | mc.FLAG_SEAM | mc.FLAG_NO_EMIT, z_begin=11, z_end=22)
+        assert (r.n_verts, r.n_tris, r.z_begin, r.z_end) == (w.n_verts, w.n_tris, 11, 22)
+        for a, b in zip(r.indexed(), w.indexed()):
+            assert np.array_equal(nanbits(a) if a.dtype == np.float32 else a, nanbits(b) if b.dtype == np.float32 else b)
+    finally:
+        c.close()
+        d.close()
 
 
 OPS = ["+", "-", "*"]

@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mc_amd as mc
 c = mc.Context(0)
 for n in (256, 512, 1024):
