@@ -203,7 +203,10 @@ int mc_set_constraint(mc_context *ctx, int i, const char *lhs, const char *op, f
  * (the reference re-derives their positions as -1 + k*step, a few ulp off), and the triangles come in sweep order, not in
  * breadth-first order.  (That set is a connected component of the surface cells; it is labelled on the device by a
  * union-find over the sweep's records, not walked.)  Whole-grid sweeps only (z_begin 0, z_end -1); not capturable by
- * mc_graph_build. */
+ * mc_graph_build.  With MC_FLAG_INDEXED the component is welded like the dense sweep (only visited cells insert
+ * vertices, marching.cpp:310-331): the reference numbers vertices and triangles in VISITATION order and keeps the position
+ * computed by the first visited cell of each vertex; here both follow the sweep order -- the same triangles over the same
+ * welded points within the reference's own 1e-6 tolerance, in another order. */
 int mc_set_seed(mc_context *ctx, float x, float y, float z);
 int mc_seed_mode(mc_context *ctx, int on);
 int mc_use_constraint(mc_context *ctx, int i, int use);

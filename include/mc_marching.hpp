@@ -26,7 +26,8 @@
 // area-weighted vertex normals (CalculateNormal, Source/normal.h:3-41, also available as a free function).
 // set_indexed(false) hands over the GPU's triangle SOUP instead (tri_list = 0..3T-1) with gradient normals.  Constraints
 // (set_constraint0..2 / use_constraint0..2) and seed mode (seed_mode / set_seed) are provided -- seed mode returns the same
-// triangles as the reference's walk, in sweep order and as soup (mc_hip.h).  The step-by-step STATE MACHINE of
+// triangles as the reference's walk, welded like the dense sweep's, in sweep order instead of visitation order (mc_hip.h).
+// The step-by-step STATE MACHINE of
 // recalculate() is not; step_at(ix, iy, iz) gives the Step_Data of any one cell instead.  A failed GPU call makes
 // recalculate() return false and last_error() non-empty instead of crashing.
 //
@@ -355,7 +356,7 @@ public:
             error_ = mc_last_error();
             return false;
         }
-        const bool indexed = indexed_ && !seed_mode_;  // seed mode hands over soup (the reference numbers its vertices in visitation order)
+        const bool indexed = indexed_;  // (seed mode too: marching.cpp:310-331 feeds add_step_to_poly_data like the dense sweep)
         mc_params p{};
         p.equation = evaluator_->equation().c_str();
         p.step = grid_step_size_;

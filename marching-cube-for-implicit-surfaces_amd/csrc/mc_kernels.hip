@@ -1945,12 +1945,23 @@ __device__ __forceinline__ int mc_snap(float iso, float c0, float c1, float v0, 
     return 0;
 }
 
+// (internal flag, set by mc_runtime) seed mode: the records of cells outside the seed's component have lost their triangles
+// (mc_seed_filter) -- the reference never visits those cells, so they insert no vertex (marching.cpp:310-331)
+#define MC_FLAG_SEEDED 0x40000000u
+__device__ __forceinline__ u32 mc_find_record_opt(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb, int qx, int qy,
+                                                  int qz);
+
 // a cell that can hold vertices: inside the sweep's ownership range (own_z_lo .. the slab's last layer) and -- with
 // constraints -- not skipped (marching.cpp:476; a skipped cell's code byte reads 0, and a cell that contains a crossed edge
 // never has code 0 or 255 otherwise).  A cell BELOW the swept layers (MC_FLAG_SEAM: the previous slab's) has no code byte
 // here: whether a constraint skips it is evaluated at its 8 corners, as the sweep that owns it does (marching.cpp:255-280).
-__device__ __forceinline__ bool mc_cell_ok(const McParams& p, const u8* __restrict__ codes, int qx, int qy, int qz) {
+__device__ __forceinline__ bool mc_cell_ok(const McParams& p, const u8* __restrict__ codes, const u32* __restrict__ recs,
+                                           const uint2* __restrict__ segcb, int qx, int qy, int qz) {
     if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.own_z_lo || qz >= p.z_begin + p.nz) return false;
+    if (p.flags & MC_FLAG_SEEDED) {  // (whole-grid sweeps only: every cell has its record here)
+        const u32 q = mc_find_record_opt(p, recs, segcb, qx, qy, qz);
+        return q != 0xFFFFFFFFu && ((recs[q] >> 17) & 7u) != 0u;
+    }
 #ifdef MC_CONS
     if (qz < p.z_begin) {
         const float* __restrict__ ax = p.axs;
@@ -1977,7 +1988,8 @@ __device__ __forceinline__ int mc_edge_of(int ax, int d0, int d1) {
 
 // owner of the vertex on edge e of cell (ix, iy, iz): cell (qx, qy, qz) and its edge qe
 // corner: the key is a lattice corner (several lattice edges' vertices are welded there), not the lattice edge
-__device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, int ix, int iy, int iz, int e, int& qx, int& qy,
+__device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, const u32* __restrict__ recs,
+                                           const uint2* __restrict__ segcb, int ix, int iy, int iz, int e, int& qx, int& qy,
                                            int& qz, int& qe, bool& corner) {
     const float* __restrict__ axis = p.axis;
     const int ax = edge_axis(e);
@@ -1999,7 +2011,7 @@ __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restri
                 int q[3] = {b[0], b[1], b[2]};
                 q[a0] -= d0;
                 q[a1] -= d1;
-                if (mc_cell_ok(p, codes, q[0], q[1], q[2])) {
+                if (mc_cell_ok(p, codes, recs, segcb, q[0], q[1], q[2])) {
                     qx = q[0];
                     qy = q[1];
                     qz = q[2];
@@ -2040,7 +2052,7 @@ __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restri
                 // the cell C - (dx, dy, dz) holds, of C's six edges, the one towards -a where its offset is 1, towards +a where 0
                 const u32 mx = (Sm >> (0 + dx)) & 1u, my = (Sm >> (2 + dy)) & 1u, mz = (Sm >> (4 + dz)) & 1u;
                 if (!(mx | my | mz)) continue;
-                if (!mc_cell_ok(p, codes, C[0] - dx, C[1] - dy, C[2] - dz)) continue;
+                if (!mc_cell_ok(p, codes, recs, segcb, C[0] - dx, C[1] - dy, C[2] - dz)) continue;
                 // their edge numbers in that cell (the lower end of an edge along a has offset 0 on a); lowest wins
                 int best = 12;
                 if (mx) best = min(best, mc_edge_of(0, dy, dz));
@@ -2136,14 +2148,15 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
         u32 ownm = 0;
-        if (valid) {
+        if (valid && !((rec >> 17) & 7u)) recown[ridx] = 0u;  // seed mode: a cell outside the seed's component (no triangles left)
+        if (valid && ((rec >> 17) & 7u)) {
             u32 m = crossed_edges((rec >> 8) & 0xFFu), cornm = 0;
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe, corner);
+                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner);
                 if (qx == ix && qy == iy && qz == iz && qe == e) {
                     ownm |= 1u << e;
                     if (corner) cornm |= 1u << e;
@@ -2233,17 +2246,17 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        if (valid) {
+        if (valid) rectri[ridx] = gtri0;  // the record's first triangle, for mc_vnormal
+        if (valid && ((rec >> 17) & 7u)) {
             const u32 code = (rec >> 8) & 0xFFu;
             const u32 myown = recown[ridx] & 0xFFFu, myvb = recvb[ridx];
-            rectri[ridx] = gtri0;  // the record's first triangle, for mc_vnormal
             u32 m = crossed_edges(code);
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, ix, iy, iz, e, qx, qy, qz, qe, corner);
+                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner);
                 u32 o = myown, vb = myvb;
                 if (qz < p.z_begin) {
                     // MC_FLAG_SEAM: the owner is a cell of the layer below the swept range (the lower plane of the ghost layer):

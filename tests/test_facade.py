@@ -180,6 +180,12 @@ def test_facade_seed_mode(mc):
                            env=dict(os.environ, MC_DEMO_SEED=seed))
         assert r.returncode == 0, r.stdout + r.stderr
         assert f" tris={tris} " in r.stdout, r.stdout
+    # the facade's default, set_indexed(true): get_poly_data() is the welded mesh in seed mode too (marching.cpp:310-331)
+    r = subprocess.run([str(build_demo(mc)), "x^2+y^2+z^2-1", "32", "0", "indexed"], capture_output=True, text=True,
+                       env=dict(os.environ, MC_DEMO_SEED="1 0 0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    verts = int(r.stdout.split("verts=")[1].split()[0])
+    assert " tris=9537 " in r.stdout and 4000 < verts < 5000, r.stdout
 
 
 @pytest.mark.gpu

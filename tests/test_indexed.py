@@ -217,14 +217,75 @@ def test_indexed_sphere_1024_properties(mc, ctx):
     assert r.ms_index > 0
 
 
-def test_indexed_refused_in_seed_mode(mc):
+def weld_soup(soup, tol=1e-6):
+    """marching.cpp:599-654 by brute force on a (T,3,3) soup, in the soup's order: first point wins, per-axis tolerance."""
+    pts = soup.reshape(-1, 3)
+    order = np.lexsort((pts[:, 2], pts[:, 1], pts[:, 0]))
+    verts, idx = [], np.empty(len(pts), np.int64)
+    grid = {}
+    for i in range(len(pts)):
+        p = pts[i]
+        key = tuple(np.floor(p.astype(np.float64) / 1e-3).astype(np.int64))
+        hit = -1
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    for j in grid.get((key[0] + dx, key[1] + dy, key[2] + dz), ()):
+                        if np.all(np.abs(verts[j] - p) < tol):
+                            hit = j if hit < 0 else min(hit, j)
+        if hit < 0:
+            hit = len(verts)
+            verts.append(p)
+            grid.setdefault(key, []).append(hit)
+        idx[i] = hit
+    return np.array(verts, np.float32).reshape(-1, 3), idx.reshape(-1, 3)
+
+
+@pytest.mark.parametrize("eq,n,seed,iso", [
+    (EQ["sphere"], 32, (1.0, 0.0, 0.0), 0.0),
+    (EQ["eq8"], 40, (0.43, 0.0, 0.0), 0.0),                                   # several components: only the seed's is welded (2 888 of 9 184 triangles)
+    (EQ["eq8"], 40, (0.66, 0.0, 0.0), 0.0),
+    ("x^2-0.25", 32, (0.5, 0.0, 0.0), 0.0),                                   # two sheets of exact lattice hits: only the seed's is welded
+    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.3, 0.2, 0.0), 0.0),  # a small sphere inside a large one
+    ("z^2-0.25", 64, (0.1, -0.2, 0.5), 0.0),                                  # whole layers of surface cells, corner keys
+])
+def test_indexed_mesh_in_seed_mode(mc, orc, eq, n, seed, iso):
+    """MC_FLAG_INDEXED with seed mode (marching.cpp:310-331 -> add_step_to_poly_data :599-654): the seed's component welded.
+    Against the oracle's restatement of the reference's walk, welded in ITS order with the reference's tolerance: the same
+    number of vertices and triangles, every triangle over the same three welded points within 1e-6 (the reference keeps the
+    position of the first VISITED cell, the device that of the first cell in sweep order); and against the device's own
+    seed-mode soup."""
+    step = step_of(n)
     c = mc.Context(0)
     try:
-        c.set_seed(1.0, 0.0, 0.0)
+        c.set_seed(*seed)
         c.seed_mode(True)
-        with pytest.raises(mc.McError) as e:
-            c.march(EQ["sphere"], step_of(16), flags=mc.FLAG_INDEXED)
-        assert e.value.code == mc.MC_ERR_ARG
+        r = c.march(eq, step, iso, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
+        v, t, nrm = r.indexed()
+        soup = r.vertices()[:, :, :3]
+        o = orc.march_seed(eq, step, seed, iso, pow_mode=orc.POW_EXACT)
+        assert r.n_tris == o.n_tris and r.n_tris > 0
+        ov, ot = weld_soup(o.soup)
+        assert r.n_verts == len(ov), (r.n_verts, len(ov))
+        # our triangles over our welded points == our soup, within the tolerance; no two welded points coincide
+        assert np.abs(v[t.reshape(-1)] - soup.reshape(-1, 3)).max() < 1e-6
+        assert np.array_equal(np.unique(t), np.arange(r.n_verts, dtype=np.uint32))
+        # the same triangle set as the reference's walk (order differs): map each of our welded points to the reference's
+        # point within its tolerance (one to one), then compare the triangles as multisets of index triples
+        from scipy.spatial import cKDTree
+        dist, m = cKDTree(ov.astype(np.float64)).query(v.astype(np.float64))
+        # (1e-5, the soup's tolerance in seed mode: the reference re-derives cell positions as previous +- step and drifts by
+        # a few ulp per move -- DESIGN.md section 4, "Seed mode")
+        assert dist.max() < 1e-5 and len(np.unique(m)) == len(ov)
+        ours = np.sort(np.ascontiguousarray(m[t.astype(np.int64)]).view([("a", np.int64), ("b", np.int64), ("c", np.int64)]).ravel())
+        refs = np.sort(np.ascontiguousarray(ot.astype(np.int64)).view([("a", np.int64), ("b", np.int64), ("c", np.int64)]).ravel())
+        assert np.array_equal(ours, refs)
+        ok = np.isfinite(nrm).all(axis=1)
+        assert ok.sum() >= r.n_verts - 8 and np.abs(np.linalg.norm(nrm[ok], axis=1) - 1).max() < 1e-5
+        # the dense sweep of the same context is untouched by it
+        c.seed_mode(False)
+        d = c.march(eq, step, iso, flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
+        assert d.n_tris >= r.n_tris and d.n_verts >= r.n_verts
     finally:
         c.close()
 
