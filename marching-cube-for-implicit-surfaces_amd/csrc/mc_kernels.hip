@@ -1988,18 +1988,24 @@ __device__ __forceinline__ int mc_edge_of(int ax, int d0, int d1) {
 
 // owner of the vertex on edge e of cell (ix, iy, iz): cell (qx, qy, qz) and its edge qe
 // corner: the key is a lattice corner (several lattice edges' vertices are welded there), not the lattice edge
+// edge_key_known: the caller knows (mc_vmark has recorded it) that the key is the lattice edge itself -- the usual case: the
+// owner then follows from lattice indices alone, no sample of f, no interpolation
 __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, const u32* __restrict__ recs,
                                            const uint2* __restrict__ segcb, int ix, int iy, int iz, int e, int& qx, int& qy,
-                                           int& qz, int& qe, bool& corner) {
+                                           int& qz, int& qe, bool& corner, bool edge_key_known = false) {
     const float* __restrict__ axis = p.axis;
     const int ax = edge_axis(e);
     int b[3] = {ix + (int)((MC_EDGE_OX >> e) & 1u), iy + (int)((MC_EDGE_OY >> e) & 1u), iz + (int)((MC_EDGE_OZ >> e) & 1u)};
-    const float x0 = axis[b[0]], y0 = axis[b[1]], z0 = axis[b[2]];
-    const int ba = ax == 0 ? b[0] : ax == 1 ? b[1] : b[2];
-    const float c0 = axis[ba], c1 = axis[ba + 1];
-    const float v0 = mc_F(p, x0, y0, z0);
-    const float v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
-    const int sn = mc_snap(p.iso, c0, c1, v0, v1);
+    int sn = 0;
+    float v0 = 0.0f, v1 = 0.0f;
+    if (!edge_key_known) {
+        const float x0 = axis[b[0]], y0 = axis[b[1]], z0 = axis[b[2]];
+        const int ba = ax == 0 ? b[0] : ax == 1 ? b[1] : b[2];
+        const float c0 = axis[ba], c1 = axis[ba + 1];
+        v0 = mc_F(p, x0, y0, z0);
+        v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
+        sn = mc_snap(p.iso, c0, c1, v0, v1);
+    }
     corner = sn != 0;
     if (sn == 0) {
         // lattice-edge key: the first of the (up to) four cells around the edge, in sweep order
@@ -2157,12 +2163,10 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
                 int qx, qy, qz, qe;
                 bool corner;
                 mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner);
-                if (qx == ix && qy == iy && qz == iz && qe == e) {
-                    ownm |= 1u << e;
-                    if (corner) cornm |= 1u << e;
-                }
+                if (qx == ix && qy == iy && qz == iz && qe == e) ownm |= 1u << e;
+                if (corner) cornm |= 1u << e;
             }
-            recown[ridx] = ownm | (cornm << 16);  // bits 0..11: owned edges; 16..27: those of them whose key is a lattice corner
+            recown[ridx] = ownm | (cornm << 16);  // bits 0..11: owned edges; 16..27: the crossed edges whose key is a lattice corner
         }
         total += (u32)__builtin_popcount(ownm);
     }
@@ -2214,13 +2218,18 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vwrite(const McPa
     }
 }
 
-// the record of cell (qx, qy, qz): its segment's records are contiguous and ascending in x
+// the record of cell (qx, qy, qz), which has one: its segment's records are contiguous and ascending in x.  Up to four
+// records are fetched at once and the one wanted is picked (a segment of a curved surface holds 1-3), longer ones are searched
 __device__ __forceinline__ u32 mc_find_record(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb, int qx, int qy,
                                               int qz) {
     const u32 seg = (u32)(((qz - p.z_begin) * p.n1 + qy) * p.nchunk + (qx >> 8));
     const uint2 cb = segcb[seg];
     u32 lo = cb.y, n = cb.x >> 16;
     const u32 want = (u32)(qx & 255);
+    if (n <= 4u) {
+        const u32 rb = recs[lo + 1u], rc_ = recs[lo + 2u], rd = recs[lo + 3u];  // (the buffer has slack behind its last record)
+        return (n > 3u && (rd & 0xFFu) <= want) ? lo + 3u : (n > 2u && (rc_ & 0xFFu) <= want) ? lo + 2u : (n > 1u && (rb & 0xFFu) <= want) ? lo + 1u : lo;
+    }
     while (n > 1u) {  // lower bound
         const u32 half = n >> 1;
         if ((recs[lo + half - 1u] & 0xFFu) < want) {
@@ -2238,25 +2247,27 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                                                                        const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                        const u8* __restrict__ codes, const u32* __restrict__ recown,
                                                                        const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris,
-                                                                       u32* __restrict__ rectri) {
+                                                                       u32* __restrict__ segtri) {
     __shared__ u32 s_eidx[MC_WPB_I][64 * 13];  // per lane: the vertex index of each of its 12 edges (stride 13: no bank conflicts)
     MC_GROUP_LDS
     u32* eidx = s_eidx[w] + 13 * lane;
+    // lane = segment: its first triangle, for mc_vnormal (a record's first triangle = its segment's + the record's prefix)
+    if (group * 64u + (u32)lane < p.nseg) segtri[group * 64u + (u32)lane] = g.trioff[lane];
     for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        if (valid) rectri[ridx] = gtri0;  // the record's first triangle, for mc_vnormal
         if (valid && ((rec >> 17) & 7u)) {
             const u32 code = (rec >> 8) & 0xFFu;
-            const u32 myown = recown[ridx] & 0xFFFu, myvb = recvb[ridx];
+            const u32 myrow = recown[ridx];
+            const u32 myown = myrow & 0xFFFu, myvb = recvb[ridx];
             u32 m = crossed_edges(code);
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner);
+                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner, ((myrow >> (16 + e)) & 1u) == 0u);
                 u32 o = myown, vb = myvb;
                 if (qz < p.z_begin) {
                     // MC_FLAG_SEAM: the owner is a cell of the layer below the swept range (the lower plane of the ghost layer):
@@ -2309,71 +2320,237 @@ __device__ __forceinline__ u32 mc_find_record_opt(const McParams& p, const u32* 
     return (recs[lo] & 0xFFu) == want ? lo : 0xFFFFFFFFu;
 }
 
-// I4: CalculateNormal (Source/normal.h:3-41) on the welded mesh, as a GATHER: one lane per vertex (= per owned edge of a
-// record) visits the cells that can hold a triangle on that vertex -- the 4 cells around its lattice edge, or, when the
-// vertex is welded to a lattice corner, the 12 cells around the edge's two ends -- in sweep order, their triangles in
-// table order, and adds cross(B-A, C-A) for every corner that IS the vertex: exactly the additions the reference performs
-// on vNormal[i], in the reference's order (its loop runs over the triangles in emission order), so the sums -- and the
-// normalised result, glm's v * (1 / sqrt(dot(v, v))) -- are the reference's bits.  (A scatter with float atomics was
-// 3.1 ms of the 3.7 ms the indexed mesh took at 1025^3: 89 M single-float atomics to scattered addresses run at a
-// seventeenth of the rate contiguous ones do, and their sums depended on arrival order.)
+// I4: CalculateNormal (Source/normal.h:3-41) on the welded mesh, as a GATHER: every vertex visits the cells that can hold a
+// triangle on it -- the 4 cells around its lattice edge, or, when the vertex is welded to a lattice corner, the 12 cells
+// around the edge's two ends -- in sweep order, their triangles in table order, and adds cross(B-A, C-A) for every corner
+// that IS the vertex: exactly the additions the reference performs on vNormal[i], in the reference's order (its loop runs
+// over the triangles in emission order), so the sums -- and the normalised result, glm's v * (1 / sqrt(dot(v, v))) -- are
+// the reference's bits.  (A scatter with float atomics was 3.1 ms of the 3.7 ms the indexed mesh took at 1025^3: 89 M
+// single-float atomics to scattered addresses run at a seventeenth of the rate contiguous ones do, and their sums depended
+// on arrival order.)
+//
+// The kernel is a chain of dependent loads per (vertex, cell): segment -> its records (binary search) -> the record's
+// triangles -> their indices -> their positions.  Round 2 walked it one lane per RECORD -- owned edges one after the other,
+// their cells one after the other: ~100 dependent round trips per chunk of records, 1.16 of the 1.70 ms the indexed mesh took
+// at 1025^3.  Now the vertices of a chunk are listed, and FOUR lanes serve one vertex, one per candidate cell: the four
+// chains run side by side and leave (normal, hits) per triangle in LDS; the vertex's first lane then adds them up in the
+// reference's order.  Vertices welded to a lattice corner (12 cells; rare unless the surface passes through lattice points)
+// take a second pass, one lane per vertex.
+#define MC_VN_CAP 256  // vertices of one kind (edge key / corner key) listed at a time; 16 records own at most 192
+// what cell (qx, qy, qz) adds to vertex v: its triangles in table order; out[t] = {cross(B-A, C-A), corners that are v}
+__device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb,
+                                           const u32* __restrict__ segtri, const u32* __restrict__ tlist, const float* __restrict__ vlist,
+                                           u64 nverts, int qx, int qy, int qz, u32 v, float4* out) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) out[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // the cell's record: segment -> its records (ascending in x).  Four dependent loads fewer than a search that ends in the
+    // record index: the segment's first triangle comes with its counts, up to four records are fetched at once and the one
+    // wanted is picked (a segment of the sphere holds 1-3), longer segments are searched
+    if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.z_begin || qz >= p.z_begin + p.nz) return;
+    const u32 seg = (u32)(((qz - p.z_begin) * p.n1 + qy) * p.nchunk + (qx >> 8));
+    const uint2 cb = segcb[seg];
+    const u32 st = segtri[seg];
+    const u32 n = cb.x >> 16, want = (u32)(qx & 255);
+    if (n == 0u) return;
+    u32 rec;
+    if (n <= 4u) {
+        const u32 ra = recs[cb.y], rb = recs[cb.y + 1u], rc_ = recs[cb.y + 2u], rd = recs[cb.y + 3u];  // (the buffer has slack behind its last record)
+        rec = (ra & 0xFFu) == want ? ra : (n > 1u && (rb & 0xFFu) == want) ? rb : (n > 2u && (rc_ & 0xFFu) == want) ? rc_ : (n > 3u && (rd & 0xFFu) == want) ? rd : 0xFFFFFFFFu;
+        if (rec == 0xFFFFFFFFu) return;
+    } else {
+        u32 lo = cb.y, m = n;
+        while (m > 1u) {  // lower bound
+            const u32 half = m >> 1;
+            if ((recs[lo + half - 1u] & 0xFFu) < want) {
+                lo += half;
+                m -= half;
+            } else {
+                m = half;
+            }
+        }
+        rec = recs[lo];
+        if ((rec & 0xFFu) != want) return;
+    }
+    const u32 nt = (rec >> 17) & 7u;
+    const u32 t0 = st + (rec >> 20);
+    u32 i1[5], i2[5], i3[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {  // (all index loads first, then all position loads: the loads of one level travel together)
+        i1[t] = i2[t] = i3[t] = 0xFFFFFFFFu;
+        if ((u32)t < nt) {
+            const u32* tri = tlist + 3ull * (t0 + (u32)t);
+            i1[t] = tri[0];
+            i2[t] = tri[1];
+            i3[t] = tri[2];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int hits = (i1[t] == v ? 1 : 0) + (i2[t] == v ? 1 : 0) + (i3[t] == v ? 1 : 0);
+        if ((u32)t >= nt || !hits || i1[t] >= nverts || i2[t] >= nverts || i3[t] >= nverts) continue;
+        const float ax_ = vlist[3ull * i1[t]], ay_ = vlist[3ull * i1[t] + 1], az_ = vlist[3ull * i1[t] + 2];
+        const float bax = vlist[3ull * i2[t]] - ax_, bay = vlist[3ull * i2[t] + 1] - ay_, baz = vlist[3ull * i2[t] + 2] - az_;
+        const float cax = vlist[3ull * i3[t]] - ax_, cay = vlist[3ull * i3[t] + 1] - ay_, caz = vlist[3ull * i3[t] + 2] - az_;
+        // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
+        out[t] = make_float4(bay * caz - cay * baz, baz * cax - caz * bax, bax * cay - cax * bay, __builtin_bit_cast(float, (u32)hits));
+    }
+}
+// vNormal[i] = normal + vNormal[i], once per corner that is the vertex (normal.h:22-31): almost always 0 or 1 times -- the
+// second and third block are skipped by the whole wave unless a degenerate triangle has the vertex at two corners
+__device__ __forceinline__ void mc_vn_add(const float4 c, float& sx, float& sy, float& sz) {
+    const u32 hits = __builtin_bit_cast(u32, c.w);
+    if (hits >= 1u) {
+        sx = c.x + sx;
+        sy = c.y + sy;
+        sz = c.z + sz;
+    }
+    if (hits >= 2u) {
+        sx = c.x + sx;
+        sy = c.y + sy;
+        sz = c.z + sz;
+    }
+    if (hits >= 3u) {
+        sx = c.x + sx;
+        sy = c.y + sy;
+        sz = c.z + sz;
+    }
+}
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                         const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                         const u32* __restrict__ recown, const u32* __restrict__ recvb,
-                                                                        const u32* __restrict__ rectri, const u32* __restrict__ tlist,
+                                                                        const u32* __restrict__ segtri, const u32* __restrict__ tlist,
                                                                         const float* __restrict__ vlist, float* __restrict__ vnrm, u64 nverts) {
+    // (LDS is what limits the waves per CU here, and the kernel lives on them: 71 % of its wave-cycles are waits for loads)
+    __shared__ unsigned short s_item[MC_WPB_I][2 * MC_VN_CAP];  // the listed vertices: record lane | edge << 6; edge keys from the front, corner keys from the back
+    __shared__ uint2 s_rc[MC_WPB_I][64];                         // per record of the chunk: {ix | iy << 16, iz}
+    __shared__ uint2 s_rv[MC_WPB_I][64];                         // ... {first vertex, owned edges}
     MC_GROUP_LDS
+    unsigned short* item = s_item[w];
+    uint2* rc = s_rc[w];
+    uint2* rv = s_rv[w];
     for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        if (!valid) continue;
-        const u32 ow = recown[ridx];
-        u32 v = recvb[ridx];
-        u32 m = ow & 0xFFFu;
-        while (m) {
-            const int e = __builtin_ctz(m);
-            m &= m - 1u;
-            const bool corner = (ow >> (16 + e)) & 1u;
-            const int ax = edge_axis(e);
-            // lower end of the lattice edge; candidate cells: offsets -1 / 0 on the two other axes, 0 on the edge's axis
-            // (edge key) or -1 / 0 / +1 (corner key: the cells around either end)
-            const int bx = ix + (int)((MC_EDGE_OX >> e) & 1u), by = iy + (int)((MC_EDGE_OY >> e) & 1u), bz = iz + (int)((MC_EDGE_OZ >> e) & 1u);
-            const int a_lo = corner ? -1 : 0, a_hi = corner ? 1 : 0;
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            for (int dz = (ax == 2 ? a_lo : -1); dz <= (ax == 2 ? a_hi : 0); ++dz)
-                for (int dy = (ax == 1 ? a_lo : -1); dy <= (ax == 1 ? a_hi : 0); ++dy)
-                    for (int dx = (ax == 0 ? a_lo : -1); dx <= (ax == 0 ? a_hi : 0); ++dx) {
-                        const u32 q = mc_find_record_opt(p, recs, segcb, bx + dx, by + dy, bz + dz);
-                        if (q == 0xFFFFFFFFu) continue;
-                        const u32 nt = (recs[q] >> 17) & 7u;
-                        const u32 t0 = rectri[q];
-                        for (u32 t = 0; t < nt; ++t) {
-                            const u32* tri = tlist + 3ull * (t0 + t);
-                            const u32 i1 = tri[0], i2 = tri[1], i3 = tri[2];
-                            const int hits = (i1 == v ? 1 : 0) + (i2 == v ? 1 : 0) + (i3 == v ? 1 : 0);
-                            if (!hits || i1 >= nverts || i2 >= nverts || i3 >= nverts) continue;
-                            const float ax_ = vlist[3ull * i1], ay_ = vlist[3ull * i1 + 1], az_ = vlist[3ull * i1 + 2];
-                            const float bax = vlist[3ull * i2] - ax_, bay = vlist[3ull * i2 + 1] - ay_, baz = vlist[3ull * i2 + 2] - az_;
-                            const float cax = vlist[3ull * i3] - ax_, cay = vlist[3ull * i3 + 1] - ay_, caz = vlist[3ull * i3 + 2] - az_;
-                            // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
-                            const float nx = bay * caz - cay * baz, ny = baz * cax - caz * bax, nz = bax * cay - cax * bay;
-                            for (int h = 0; h < hits; ++h) {  // vNormal[i] = normal + vNormal[i], once per corner that is the vertex
-                                sx = nx + sx;
-                                sy = ny + sy;
-                                sz = nz + sz;
-                            }
+        const u32 ow = valid ? recown[ridx] : 0u;
+        rc[lane] = make_uint2((u32)ix | ((u32)iy << 16), (u32)iz);
+        rv[lane] = make_uint2(valid ? recvb[ridx] : 0u, ow & 0xFFFu);
+        // the chunk's vertices are listed all at once when they fit, else 16 records at a time (which always fit)
+        int nsub = 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int lo = nsub == 1 ? 0 : 16 * sub, hi = nsub == 1 ? 64 : lo + 16;
+            const u32 own = (lane >= lo && lane < hi) ? ow & 0xFFFu : 0u, corn = (ow >> 16) & own;
+            const u32 ne = (u32)__builtin_popcount(own & ~corn), nc = (u32)__builtin_popcount(corn);
+            const u32 ie = wave_inclusive_scan(ne), ic = wave_inclusive_scan(nc);
+            const u32 NE = (u32)__builtin_amdgcn_readlane((int)ie, 63), NC = (u32)__builtin_amdgcn_readlane((int)ic, 63);
+            if (nsub == 1 && (NE > (u32)MC_VN_CAP || NC > (u32)MC_VN_CAP)) {
+                nsub = 4;
+                sub = -1;
+                continue;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                u32 m = own & ~corn, j = ie - ne;
+                while (m) {
+                    const u32 e = (u32)__builtin_ctz(m);
+                    m &= m - 1u;
+                    item[j++] = (unsigned short)((u32)lane | (e << 6));
+                }
+                m = corn;
+                j = 2u * MC_VN_CAP - 1u - (ic - nc);
+                while (m) {
+                    const u32 e = (u32)__builtin_ctz(m);
+                    m &= m - 1u;
+                    item[j--] = (unsigned short)((u32)lane | (e << 6));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- vertices whose key is their lattice edge: 16 per round, lane = 4 * vertex + cell (cells in sweep order).  The
+            // sum travels through the four lanes of a vertex (DPP, one lane to the right per step): lane j adds its cell's
+            // triangles to what the cells before it have summed -- the reference's additions in the reference's order, no LDS
+            for (u32 k0 = 0; k0 < NE; k0 += 16u) {
+                const u32 k = k0 + ((u32)lane >> 2), j = (u32)lane & 3u;
+                float4 mine[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) mine[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                u32 v = 0xFFFFFFFFu;
+                if (k < NE) {
+                    const u32 it = item[k];
+                    const int e = (int)(it >> 6);
+                    const uint2 c = rc[it & 63u];
+                    const uint2 o = rv[it & 63u];
+                    v = o.x + (u32)__builtin_popcount(o.y & ((1u << e) - 1u));
+                    const int ax = edge_axis(e);
+                    // lower end of the lattice edge; the cells around it: offsets -1 / 0 on the two other axes, the slower axis first
+                    int b[3] = {(int)(c.x & 0xFFFFu) + (int)((MC_EDGE_OX >> e) & 1u), (int)(c.x >> 16) + (int)((MC_EDGE_OY >> e) & 1u),
+                                (int)c.y + (int)((MC_EDGE_OZ >> e) & 1u)};
+                    const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
+                    b[a1] -= 1 - (int)(j >> 1);
+                    b[a0] -= 1 - (int)(j & 1u);
+                    mc_vn_cell(p, recs, segcb, segtri, tlist, vlist, nverts, b[0], b[1], b[2], v, mine);
+                }
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+                for (u32 step = 0; step < 4u; ++step) {
+                    if (j == step) {
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) mc_vn_add(mine[t], sx, sy, sz);
+                    }
+                    if (step < 3u) {  // hand the sum to the next lane (row_shr:1; lanes 4 k .. 4 k + 3 sit in one DPP row)
+                        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x111, 0xf, 0xf, false));
+                        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x111, 0xf, 0xf, false));
+                        const float tz = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sz), 0x111, 0xf, 0xf, false));
+                        if (j == step + 1u) {
+                            sx = tx;
+                            sy = ty;
+                            sz = tz;
                         }
                     }
-            if ((u64)v < nverts) {
-                const float d = (sx * sx + sy * sy) + sz * sz;
-                const float inv = 1.0f / __builtin_sqrtf(d);  // glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt
-                vnrm[3ull * v] = sx * inv;
-                vnrm[3ull * v + 1] = sy * inv;
-                vnrm[3ull * v + 2] = sz * inv;
+                }
+                if (j == 3u && k < NE && (u64)v < nverts) {
+                    const float d = (sx * sx + sy * sy) + sz * sz;
+                    const float inv = 1.0f / __builtin_sqrtf(d);  // glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt
+                    vnrm[3ull * v] = sx * inv;
+                    vnrm[3ull * v + 1] = sy * inv;
+                    vnrm[3ull * v + 2] = sz * inv;
+                }
             }
-            ++v;
+            // ---- vertices welded to a lattice corner: one lane per vertex, the 12 cells around the edge's two ends in sweep order
+            for (u32 k0 = 0; k0 < NC; k0 += 64u) {
+                const u32 k = k0 + (u32)lane;
+                if (k >= NC) continue;
+                const u32 it = item[2u * MC_VN_CAP - 1u - k];
+                const int e = (int)(it >> 6);
+                const uint2 c = rc[it & 63u];
+                const uint2 o = rv[it & 63u];
+                const u32 v = o.x + (u32)__builtin_popcount(o.y & ((1u << e) - 1u));
+                const int ax = edge_axis(e);
+                const int bx = (int)(c.x & 0xFFFFu) + (int)((MC_EDGE_OX >> e) & 1u), by = (int)(c.x >> 16) + (int)((MC_EDGE_OY >> e) & 1u),
+                          bz = (int)c.y + (int)((MC_EDGE_OZ >> e) & 1u);
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+                for (int dz = -1; dz <= (ax == 2 ? 1 : 0); ++dz)
+                    for (int dy = -1; dy <= (ax == 1 ? 1 : 0); ++dy)
+                        for (int dx = -1; dx <= (ax == 0 ? 1 : 0); ++dx) {
+                            float4 cc[5];
+                            mc_vn_cell(p, recs, segcb, segtri, tlist, vlist, nverts, bx + dx, by + dy, bz + dz, v, cc);
+#pragma unroll
+                            for (int t = 0; t < 5; ++t) mc_vn_add(cc[t], sx, sy, sz);
+                        }
+                if ((u64)v < nverts) {
+                    const float d = (sx * sx + sy * sy) + sz * sz;
+                    const float inv = 1.0f / __builtin_sqrtf(d);
+                    vnrm[3ull * v] = sx * inv;
+                    vnrm[3ull * v + 1] = sy * inv;
+                    vnrm[3ull * v + 2] = sz * inv;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

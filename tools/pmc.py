@@ -28,9 +28,13 @@ outdir = os.path.join(repo, "gpurun_out", "pmc_" + os.path.basename(out_json).re
 env = dict(os.environ, TMPDIR="/tmp")
 if extra:
     env["MC_JIT_EXTRA"] = extra
-cmd = ["rocprofv3", "--pmc", *counters, "-d", outdir, "-o", "run", "--output-format", "csv", "--",
-       sys.executable, os.path.join(repo, "bench.py"), *([] if "--steps" in bench_args else ["--steps", "3", "--warmup", "1"]),
-       *([] if "--mode" in bench_args else ["--no-cpu-baseline"]), *bench_args]
+if os.environ.get("PMC_SCRIPT"):   # another driver than bench.py (e.g. tools/index_probe.py)
+    cmd = ["rocprofv3", "--pmc", *counters, "-d", outdir, "-o", "run", "--output-format", "csv", "--",
+           sys.executable, os.path.join(repo, os.environ["PMC_SCRIPT"]), *bench_args]
+else:
+    cmd = ["rocprofv3", "--pmc", *counters, "-d", outdir, "-o", "run", "--output-format", "csv", "--",
+           sys.executable, os.path.join(repo, "bench.py"), *([] if "--steps" in bench_args else ["--steps", "3", "--warmup", "1"]),
+           *([] if "--mode" in bench_args else ["--no-cpu-baseline"]), *bench_args]
 import signal
 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
 try:
