@@ -1732,6 +1732,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     __shared__ u32 s_act[MC_WPB_E][66];
     __shared__ u32 s_tri[MC_WPB_E][64];
     __shared__ u32 s_rbase[MC_WPB_E][64];
+    __shared__ u32 s_next[MC_WPB_E];  // per group of the workgroup: the next chunk of records nobody has taken yet
     // the whole lattice coordinate table (n1+1 <= 2002 floats): the vertex phase gathers 6
     // coordinates per vertex, and vmcnt retires in order -- a global gather issued after the
     // previous iteration's vertex stores would wait for those stores to land
@@ -1777,21 +1778,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     // rec_overflow: mc_classify ran out of record space (the host grows the buffer and sweeps again)
     const bool mine = in_range && g0.y != g1.y && rec_overflow == 0u;  // 64 segments with an active cell
     if (!__syncthreads_or(mine ? 1 : 0)) return;  // also the barrier that publishes the tables
-    if (!mine) return;
-    {
+    // (from here on every wave of the workgroup stays: a wave whose own group is empty helps the others, below)
+    const u32 ctri = mine ? cnt & 0xFFFFu : 0u, cact = mine ? cnt >> 16 : 0u;
     // the scan gives the group's first triangle; the prefix inside the group is a wavefront scan of
     // the per-segment counts (triangles | active cells << 16)
-    const u32 ctri = cnt & 0xFFFFu, cact = cnt >> 16;
     const u32 itri = wave_inclusive_scan(ctri), iact = wave_inclusive_scan(cact);
-    const uint2 o0 = make_uint2(g0.x + (itri - ctri), iact - cact);  // {first triangle, group-local first record}
-    const u32 act_base = 0u;
-    const u32 nrec = (u32)__builtin_amdgcn_readlane((int)iact, 63);  // records of the group
-
-    u32* list = s_list[w];
-    u32* segrec = s_seg[w];
-    u32* actoff = s_act[w];
-    u32* trioff = s_tri[w];
-    u32* rbase = s_rbase[w];
     const int n1 = p.n1;
     {
         const u32 sg = min(seg, p.nseg - 1u);
@@ -1799,17 +1790,28 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
         const u32 ch = sg - rowidx * (u32)p.nchunk;
         const u32 lz = rowidx / (u32)n1;
         const u32 iy = rowidx - lz * (u32)n1;
-        segrec[lane] = iy | ((u32)(p.z_begin + (int)lz) << 11) | (ch << 22);
-        actoff[lane] = o0.y - act_base;
-        trioff[lane] = o0.x;
-        rbase[lane] = cb.y;
-        if (lane == 63) actoff[64] = nrec;
+        s_seg[w][lane] = iy | ((u32)(p.z_begin + (int)lz) << 11) | (ch << 22);
+        s_act[w][lane] = iact - cact;            // group-local first record of the segment
+        s_tri[w][lane] = g0.x + (itri - ctri);   // its first triangle
+        s_rbase[w][lane] = cb.y;
+        if (lane == 63) {
+            s_act[w][64] = iact;                 // records of the group
+            s_next[w] = 0u;
+        }
     }
     const float h = 0.5f * p.step;
     const bool want_normals = (p.flags & 1u) != 0u;
+    // The groups of a workgroup differ in work by up to 10x (a group where the surface runs along the rows holds hundreds of
+    // records, its neighbours a few dozen), and a workgroup keeps its LDS and its wave slots until its last wave is done:
+    // round 2's "one wave, one group" left 19 of a CU's 32 wave slots busy on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES).
+    // Now the unit of work is a CHUNK of 64 records of any of the workgroup's groups: a wave takes the chunks of its own
+    // group first (an LDS counter per group), then those of the groups of its neighbours, until all are taken.
+    __syncthreads();  // every wave's segment tables and chunk counter are in LDS
 
-    u32 nlist = 0;                                             // triangles staged
-    u32 listbase = (u32)__builtin_amdgcn_readfirstlane((int)o0.x);  // global index of list[0]
+    u32* list = s_list[w];
+    u32 nlist = 0;     // triangles staged
+    u32 listbase = 0;  // global index of list[0]
+    const u32* segrec = s_seg[w];  // the tables of the group the current chunk belongs to
 
     // drains the staged triangles: one lane per vertex
     auto flush = [&]() {
@@ -1889,35 +1891,45 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
         nlist = 0;
     };
 
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (u32 r0 = 0; r0 < nrec; r0 += 64u) {
-        const u32 r = r0 + (u32)lane;
-        const bool valid = r < nrec;
-        // owning segment: the largest s with actoff[s] <= r (empty segments repeat the value)
-        u32 lo = 0, hi = 64;
+
+    for (int dw = 0; dw < MC_WPB_E; ++dw) {
+        const int wv = (w + dw) & (MC_WPB_E - 1);  // MC_WPB_E is a power of two
+        const u32* actoff = s_act[wv];
+        const u32* trioff = s_tri[wv];
+        const u32* rbase = s_rbase[wv];
+        const u32 nrec = actoff[64];
+        segrec = s_seg[wv];
+        for (;;) {
+            u32 r0 = 0u;
+            if (lane == 0) r0 = __hip_atomic_fetch_add(&s_next[wv], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            r0 = (u32)__builtin_amdgcn_readfirstlane((int)r0);
+            if (r0 >= nrec) break;
+            const u32 r = r0 + (u32)lane;
+            const bool valid = r < nrec;
+            // owning segment: the largest s with actoff[s] <= r (empty segments repeat the value)
+            u32 lo = 0, hi = 64;
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const u32 mid = (lo + hi) >> 1;
-            if (actoff[mid] <= r) lo = mid; else hi = mid;
+            for (int it = 0; it < 6; ++it) {
+                const u32 mid = (lo + hi) >> 1;
+                if (actoff[mid] <= r) lo = mid; else hi = mid;
+            }
+            u32 rec = 0, gtri0 = 0;
+            if (valid) {
+                rec = recs[rbase[lo] + (r - actoff[lo])];
+                gtri0 = trioff[lo] + (rec >> 20);
+            }
+            const u32 nt = (rec >> 17) & 7u;
+            // the chunk's triangles are one contiguous range of the global order
+            const int lv = (int)min(63u, nrec - 1u - r0);
+            listbase = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
+            nlist = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), lv) - listbase;
+            const u32 base = gtri0 - listbase;
+            const u32 item = lo | ((rec & 0xFFu) << 6) | (((rec >> 8) & 0xFFu) << 14) | (((rec >> 16) & 1u) << 22);
+            for (u32 t = 0; t < nt; ++t) list[base + t] = item | (t << 23);
+            // (drained chunk by chunk: staging consecutive chunks of a group together, up to MC_LIST_CAP triangles, saves the
+            // partly filled last step of each drain but makes the units coarser -- measured the same or slower)
+            if (nlist) flush();
         }
-        u32 rec = 0, gtri0 = 0;
-        if (valid) {
-            rec = recs[rbase[lo] + (r - actoff[lo])];
-            gtri0 = trioff[lo] + (rec >> 20);
-        }
-        const u32 nt = (rec >> 17) & 7u;
-        // the chunk's triangles are one contiguous range of the global order
-        const int lv = (int)min(63u, nrec - 1u - r0);
-        const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
-        const u32 chunk_t = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), lv) - first;
-        if (nlist + chunk_t > MC_LIST_CAP) flush();
-        const u32 base = (gtri0 - listbase) & 0xFFFFFFFFu;
-        const u32 item = lo | ((rec & 0xFFu) << 6) | (((rec >> 8) & 0xFFu) << 14) | (((rec >> 16) & 1u) << 22);
-        for (u32 t = 0; t < nt; ++t) list[base + t] = item | (t << 23);
-        nlist += chunk_t;
-    }
-    if (nlist) flush();
     }
 }
 
