@@ -2154,14 +2154,57 @@ __device__ __forceinline__ bool mc_group_record(const McGroup& g, const u32* __r
     g.rbase = s_rb[w];                                                      \
     if (!mc_group_setup(p, segcb, grpoff, group, lane, g)) return;
 
+// The same for kernels whose chunks of 64 records are independent of each other: the waves of a workgroup SHARE the chunks
+// of its four groups (an LDS counter per group; a wave takes its own group's chunks first, then its neighbours') -- groups
+// differ in work by 10x and a workgroup keeps its resources until its last wave is done (see mc_emit_direct).  The kernel
+// body runs once per chunk with `g` the chunk's group and `r0` its first record.
+#define MC_GROUP_LDS_SHARED_BEGIN                                                                                       \
+    __shared__ u32 s_seg[MC_WPB_I][64], s_act[MC_WPB_I][66], s_tri[MC_WPB_I][64], s_rb[MC_WPB_I][64], s_next[MC_WPB_I]; \
+    const int lane = threadIdx.x & 63;                                                                                  \
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                                             \
+    const McParams p = *P;                                                                                              \
+    const u32 ngroups = (p.nseg + 63u) / 64u;                                                                           \
+    const u32 group = blockIdx.x * (u32)MC_WPB_I + (u32)w;                                                              \
+    if (p.overflow[0] != 0u) return;                                                                                    \
+    {                                                                                                                   \
+        McGroup g0_;                                                                                                    \
+        g0_.segrec = s_seg[w];                                                                                          \
+        g0_.actoff = s_act[w];                                                                                          \
+        g0_.trioff = s_tri[w];                                                                                          \
+        g0_.rbase = s_rb[w];                                                                                            \
+        if (group >= ngroups || !mc_group_setup(p, segcb, grpoff, group, lane, g0_)) {                                  \
+            if (lane == 63) s_act[w][64] = 0u;                                                                          \
+        }                                                                                                               \
+        if (lane == 0) s_next[w] = 0u;                                                                                  \
+    }                                                                                                                   \
+    __syncthreads();                                                                                                    \
+    for (int dw_ = 0; dw_ < MC_WPB_I; ++dw_) {                                                                          \
+        const int wv = (w + dw_) & (MC_WPB_I - 1);                                                                      \
+        McGroup g;                                                                                                      \
+        g.segrec = s_seg[wv];                                                                                           \
+        g.actoff = s_act[wv];                                                                                           \
+        g.trioff = s_tri[wv];                                                                                           \
+        g.rbase = s_rb[wv];                                                                                             \
+        g.nrec = s_act[wv][64];                                                                                         \
+        g.tri0 = 0u;                                                                                                    \
+        for (;;) {                                                                                                      \
+            u32 r0 = 0u;                                                                                                \
+            if (lane == 0) r0 = __hip_atomic_fetch_add(&s_next[wv], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            r0 = (u32)__builtin_amdgcn_readfirstlane((int)r0);                                                          \
+            if (r0 >= g.nrec) break;
+#define MC_GROUP_LDS_SHARED_END \
+        }                       \
+    }
+
 // I1: per record, the edges whose vertex this cell owns (first of the sweep to produce the key); per group, their number
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                       const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                       const u8* __restrict__ codes, u32* __restrict__ recown,
                                                                       u64* __restrict__ grpv) {
-    MC_GROUP_LDS
-    u32 total = 0;
-    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+    __shared__ u32 s_cnt[MC_WPB_I];  // vertices owned by the records of each of the workgroup's groups
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = 0u;  // (in front of the macro's barrier)
+    MC_GROUP_LDS_SHARED_BEGIN
+    {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
@@ -2180,10 +2223,12 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
             }
             recown[ridx] = ownm | (cornm << 16);  // bits 0..11: owned edges; 16..27: the crossed edges whose key is a lattice corner
         }
-        total += (u32)__builtin_popcount(ownm);
+        const u32 sum = wave_inclusive_scan((u32)__builtin_popcount(ownm));
+        if (lane == 63 && sum) __hip_atomic_fetch_add(&s_cnt[wv], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    const u32 sum = wave_inclusive_scan(total);
-    if (lane == 63) grpv[group] = (u64)sum;
+    MC_GROUP_LDS_SHARED_END
+    __syncthreads();
+    if (lane == 0 && group < ngroups) grpv[group] = (u64)s_cnt[w];
 }
 
 // I2: number the vertices (group offset from the scan + prefix over the group's records) and write the owned ones
@@ -2261,11 +2306,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                                                                        const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris,
                                                                        u32* __restrict__ segtri) {
     __shared__ u32 s_eidx[MC_WPB_I][64 * 13];  // per lane: the vertex index of each of its 12 edges (stride 13: no bank conflicts)
-    MC_GROUP_LDS
-    u32* eidx = s_eidx[w] + 13 * lane;
-    // lane = segment: its first triangle, for mc_vnormal (a record's first triangle = its segment's + the record's prefix)
-    if (group * 64u + (u32)lane < p.nseg) segtri[group * 64u + (u32)lane] = g.trioff[lane];
-    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+    u32* eidx = s_eidx[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))] + 13 * (threadIdx.x & 63);
+    MC_GROUP_LDS_SHARED_BEGIN
+    // lane = segment: its first triangle, for mc_vnormal (a record's first triangle = its segment's + the record's prefix);
+    // written with the group's first chunk
+    if (r0 == 0u && (blockIdx.x * (u32)MC_WPB_I + (u32)wv) * 64u + (u32)lane < p.nseg)
+        segtri[(blockIdx.x * (u32)MC_WPB_I + (u32)wv) * 64u + (u32)lane] = g.trioff[lane];
+    {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
@@ -2309,6 +2356,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
             }
         }
     }
+    MC_GROUP_LDS_SHARED_END
 }
 
 // the record of cell (qx, qy, qz), or ~0 when that cell is outside the slab or has none (no surface / skipped)
@@ -2436,11 +2484,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
     __shared__ unsigned short s_item[MC_WPB_I][2 * MC_VN_CAP];  // the listed vertices: record lane | edge << 6; edge keys from the front, corner keys from the back
     __shared__ uint2 s_rc[MC_WPB_I][64];                         // per record of the chunk: {ix | iy << 16, iz}
     __shared__ uint2 s_rv[MC_WPB_I][64];                         // ... {first vertex, owned edges}
-    MC_GROUP_LDS
+    MC_GROUP_LDS_SHARED_BEGIN
     unsigned short* item = s_item[w];
     uint2* rc = s_rc[w];
     uint2* rv = s_rv[w];
-    for (u32 r0 = 0; r0 < g.nrec; r0 += 64u) {
+    {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
@@ -2564,6 +2612,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    MC_GROUP_LDS_SHARED_END
 }
 
 // =============================================================== evaluate points
