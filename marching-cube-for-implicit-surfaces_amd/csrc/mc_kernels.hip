@@ -1892,20 +1892,27 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     };
 
 
-    for (int dw = 0; dw < MC_WPB_E; ++dw) {
-        const int wv = (w + dw) & (MC_WPB_E - 1);  // MC_WPB_E is a power of two
-        const u32* actoff = s_act[wv];
-        const u32* trioff = s_tri[wv];
-        const u32* rbase = s_rbase[wv];
-        const u32 nrec = actoff[64];
-        segrec = s_seg[wv];
-        for (;;) {
+    // The next chunk is taken -- and its records are requested -- BEFORE the current chunk's vertices are stored: vmcnt
+    // retires in order, so the load is back long before the stores have drained, and the wave never waits a memory round
+    // trip between two chunks.
+    int dw = 0;  // the group this wave is taking chunks from: (w + dw) mod MC_WPB_E (MC_WPB_E is a power of two)
+    struct Unit {
+        int wv;        // whose group
+        u32 r0, nrec;  // first record of the chunk, records of the group
+        u32 lo, rec;   // lane = record: its segment, the record word
+    };
+    auto take = [&](Unit& u) __attribute__((always_inline)) {
+        u.rec = 0u;
+        u.lo = 0u;
+        for (; dw < MC_WPB_E; ++dw) {
+            u.wv = (w + dw) & (MC_WPB_E - 1);
+            const u32* actoff = s_act[u.wv];
+            u.nrec = actoff[64];
             u32 r0 = 0u;
-            if (lane == 0) r0 = __hip_atomic_fetch_add(&s_next[wv], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            r0 = (u32)__builtin_amdgcn_readfirstlane((int)r0);
-            if (r0 >= nrec) break;
-            const u32 r = r0 + (u32)lane;
-            const bool valid = r < nrec;
+            if (lane == 0) r0 = __hip_atomic_fetch_add(&s_next[u.wv], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            u.r0 = (u32)__builtin_amdgcn_readfirstlane((int)r0);
+            if (u.r0 >= u.nrec) continue;
+            const u32 r = u.r0 + (u32)lane;
             // owning segment: the largest s with actoff[s] <= r (empty segments repeat the value)
             u32 lo = 0, hi = 64;
 #pragma unroll
@@ -1913,23 +1920,32 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
                 const u32 mid = (lo + hi) >> 1;
                 if (actoff[mid] <= r) lo = mid; else hi = mid;
             }
-            u32 rec = 0, gtri0 = 0;
-            if (valid) {
-                rec = recs[rbase[lo] + (r - actoff[lo])];
-                gtri0 = trioff[lo] + (rec >> 20);
-            }
-            const u32 nt = (rec >> 17) & 7u;
-            // the chunk's triangles are one contiguous range of the global order
-            const int lv = (int)min(63u, nrec - 1u - r0);
-            listbase = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
-            nlist = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), lv) - listbase;
-            const u32 base = gtri0 - listbase;
-            const u32 item = lo | ((rec & 0xFFu) << 6) | (((rec >> 8) & 0xFFu) << 14) | (((rec >> 16) & 1u) << 22);
-            for (u32 t = 0; t < nt; ++t) list[base + t] = item | (t << 23);
-            // (drained chunk by chunk: staging consecutive chunks of a group together, up to MC_LIST_CAP triangles, saves the
-            // partly filled last step of each drain but makes the units coarser -- measured the same or slower)
-            if (nlist) flush();
+            u.lo = lo;
+            if (r < u.nrec) u.rec = recs[s_rbase[u.wv][lo] + (r - actoff[lo])];
+            return true;
         }
+        return false;
+    };
+    Unit cur, nxt;
+    bool have = take(cur);
+    while (have) {
+        const bool have_next = take(nxt);  // (its record load is in flight across this chunk's work)
+        segrec = s_seg[cur.wv];
+        const u32 rec = cur.rec, lo = cur.lo;
+        const u32 gtri0 = s_tri[cur.wv][lo] + (rec >> 20);
+        const u32 nt = (rec >> 17) & 7u;  // (lanes beyond the group's records hold rec = 0)
+        // the chunk's triangles are one contiguous range of the global order
+        const int lv = (int)min(63u, cur.nrec - 1u - cur.r0);
+        listbase = (u32)__builtin_amdgcn_readfirstlane((int)gtri0);
+        nlist = (u32)__builtin_amdgcn_readlane((int)(gtri0 + nt), lv) - listbase;
+        const u32 base = gtri0 - listbase;
+        const u32 item = lo | ((rec & 0xFFu) << 6) | (((rec >> 8) & 0xFFu) << 14) | (((rec >> 16) & 1u) << 22);
+        for (u32 t = 0; t < nt; ++t) list[base + t] = item | (t << 23);
+        // (drained chunk by chunk: staging consecutive chunks of a group together, up to MC_LIST_CAP triangles, saves the
+        // partly filled last step of each drain but makes the units coarser -- measured the same or slower)
+        if (nlist) flush();
+        cur = nxt;
+        have = have_next;
     }
 }
 
