@@ -52,7 +52,13 @@ enum {
     MC_FLAG_TILE1 = 8u,        /* diagnostic: classify with row tiles of height 1 (no sample reuse)   */
     MC_FLAG_INDEXED = 32u,     /* also build the reference's indexed Poly_Data on the GPU: welded      */
                                /* vertex_list / tri_list (marching.cpp:599-654, marching.h:32-55) and  */
-                               /* the drawer's area-weighted vertex normals (normal.h:3-41)           */
+                               /* the drawer's area-weighted vertex normals (normal.h:3-41).           */
+                               /* DEVIATION: a closed form of the reference's std::set welding -- bit  */
+                               /* for bit its mesh unless two points are closer than its 1e-6 tolerance */
+                               /* WITHOUT being bit-identical; such groups are always merged here,     */
+                               /* while the reference's (non-transitive) comparator sometimes keeps    */
+                               /* them apart (4 of 3 392 vertices on x^2+y^2-0.5 at grid_res 300, see  */
+                               /* the note under mc_copy_indexed and DESIGN.md section 4)              */
     MC_FLAG_NO_CULL = 64u,     /* diagnostic: classify every row by sampling (no interval culling);   */
                                /* the output must not change                                          */
     MC_FLAG_NO_TIMING = 128u,  /* no per-kernel hipEvents (ms_* stay 0): four fewer nodes per sweep   */
@@ -171,7 +177,15 @@ int mc_copy_vertices(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_soup(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
 /* mc_copy_indexed: the indexed mesh of the last MC_FLAG_INDEXED sweep: vertex_list (n_verts*3 floats), tri_list
- * (n_tris*3 uint32) and the area-weighted vertex normals (n_verts*3 floats); any of the three may be NULL. */
+ * (n_tris*3 uint32) and the area-weighted vertex normals (n_verts*3 floats); any of the three may be NULL.
+ * The welding rule (checked against a replay of the reference's std::set, tests/test_indexed.py, tests/weld_model.py): a
+ * vertex's KEY is the lattice corner it sits on when its lattice edge's intersection point -- computed from the edge's
+ * lower end, whatever direction the owning cell's table walks it in -- lies within 1e-6 of an end of that edge, else the
+ * lattice edge itself; the first cell of the sweep that produces a key owns the vertex and its position is the one THAT
+ * cell computes.  (Lower-end and upper-end interpolation differ by an ulp at most, far below the 1e-6 threshold; a point
+ * exactly at the threshold could be keyed differently from the reference's comparison of the stored points -- one of the
+ * near-tie cases of the DEVIATION noted at MC_FLAG_INDEXED, pinned by
+ * tests/test_indexed.py::test_indexed_known_deviation_from_the_std_set_is_pinned.) */
 int mc_copy_indexed(mc_context *ctx, float *vertex_list, uint32_t *tri_list, float *normals, uint64_t max_verts,
                     uint64_t max_tris);
 /* One Poly_Data across Z slabs (marching.h:26-30 for a grid swept in parts, one slab per GPU).  Without MC_FLAG_SEAM a slab

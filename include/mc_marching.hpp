@@ -21,8 +21,10 @@
 //                                                instead of the Win32 dialog
 //
 // Differences, all documented in DESIGN.md.  get_poly_data() holds the reference's INDEXED mesh (vertex_list welded,
-// tri_list indexing it), built on the GPU with the reference's own welding rule (marching.cpp:599-654, marching.h:32-55:
-// first point inserted wins, 1e-6 tolerance; MC_FLAG_INDEXED), plus `normal_list`, an extra member: the drawer's
+// tri_list indexing it), built on the GPU with a closed form of the reference's welding rule (marching.cpp:599-654,
+// marching.h:32-55: first point inserted wins, 1e-6 tolerance; MC_FLAG_INDEXED -- identical to the reference's std::set
+// except where points lie within 1e-6 of each other without being bit-identical, which are always merged here: mc_hip.h),
+// plus `normal_list`, an extra member: the drawer's
 // area-weighted vertex normals (CalculateNormal, Source/normal.h:3-41, also available as a free function).
 // set_indexed(false) hands over the GPU's triangle SOUP instead (tri_list = 0..3T-1) with gradient normals.  Constraints
 // (set_constraint0..2 / use_constraint0..2) and seed mode (seed_mode / set_seed) are provided -- seed mode returns the same

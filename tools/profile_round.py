@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Collect the round's profile set on the GPU box (run from the repo root):
 
-    python tools/profile_round.py [--tag r02] [--workloads sphere1024,torus512,gyroid1024,goursat512]
+    python tools/profile_round.py [--tag r03] [--workloads sphere1024,torus512,gyroid1024,goursat512]
 
 Per workload (BASELINE.json configs 2/headline, 3, 4, 5):
   1. rocprofv3 --kernel-trace --stats of the bench command, with one sweep in flight (kernels alone: the durations the
@@ -22,7 +22,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r02"
+tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r03"
 wl = (sys.argv[sys.argv.index("--workloads") + 1] if "--workloads" in sys.argv else "sphere1024,torus512,gyroid1024,goursat512").split(",")
 out = os.path.join(ROOT, "gpurun_out", "profile")
 prof = os.path.join(ROOT, "profiles")
