@@ -626,29 +626,93 @@ extern "C" __global__ __launch_bounds__(64) void mc_cc_seed(const u32* __restric
     roots[0] = n;
 }
 
-// one lane per segment: records outside the seed's component lose their triangles; the segment's triangle prefix, its
-// counts and the group sums are rebuilt
+// Records outside the seed's component lose their triangles; every segment's triangle prefixes, its counts and the group sums
+// are rebuilt.  One wave per GROUP of 64 segments, lane = record in chunks of 64 (round 2 put one lane on a SEGMENT and
+// walked its records one after the other -- 256 dependent steps where a row lies in the surface -- and issued one 64-bit
+// atomic per segment; now the prefix inside a segment is a segmented wave scan plus a per-segment carry in LDS, and a group
+// costs ONE atomic).
+__device__ __forceinline__ u32 sf_scan(u32 v) {  // wavefront inclusive prefix sum (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31)
+    u32 x = v;
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 extern "C" __global__ __launch_bounds__(256) void mc_seed_filter(u32* __restrict__ recs, uint2* __restrict__ segcb, const u32* __restrict__ parent,
                                                        const u32* __restrict__ roots, u32 nseg, u64* __restrict__ grpsum,
                                                        const u32* __restrict__ overflow) {
-    const u32 seg = blockIdx.x * 256u + threadIdx.x;
-    if (seg >= nseg || overflow[0] != 0u) return;
-    const uint2 cb = segcb[seg];
+    __shared__ u32 s_act[4][66];   // per segment of the group: its first record (group-local), [64] = records of the group
+    __shared__ u32 s_tot[4][64];   // ... triangles kept so far
+    __shared__ u32 s_rb[4][64];    // ... its first record in recs
+    const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6);
+    const u32 group = blockIdx.x * 4u + (u32)w;
+    const u32 ngroups = (nseg + 63u) / 64u;
+    if (group >= ngroups || overflow[0] != 0u) return;  // (whole waves; no workgroup barrier below)
+    const u32 seg = group * 64u + (u32)lane;
+    const uint2 cb = seg < nseg ? segcb[seg] : make_uint2(0u, 0u);
     const u32 act = cb.x >> 16;
-    if (act == 0u) return;
+    const u32 iact = sf_scan(act);
+    const u32 nrec = (u32)__builtin_amdgcn_readlane((int)iact, 63);
+    if (nrec == 0u) return;
+    s_act[w][lane] = iact - act;
+    s_tot[w][lane] = 0u;
+    s_rb[w][lane] = cb.y;
+    if (lane == 63) s_act[w][64] = nrec;
     const u32 nroots = roots[0];
-    u32 tris = 0u;
-    for (u32 k = 0; k < act; ++k) {
-        u32 r = recs[cb.y + k];
-        u32 nt = (r >> 17) & 7u;
-        const u32 root = parent[cb.y + k];
-        bool keep = false;
-        for (u32 i = 1u; i <= nroots; ++i) keep = keep || root == roots[i];
-        if (!keep) nt = 0u;
-        r = (r & 0x1FFFFu) | (nt << 17) | (tris << 20);
-        recs[cb.y + k] = r;
-        tris += nt;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 r0 = 0; r0 < nrec; r0 += 64u) {
+        const u32 r = r0 + (u32)lane;
+        const bool valid = r < nrec;
+        u32 lo = 0, hi = 64;  // owning segment: the largest s with s_act[s] <= r (empty segments repeat the value)
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_act[w][mid] <= r) lo = mid; else hi = mid;
+        }
+        const u32 idx = s_rb[w][lo] + (r - s_act[w][lo]);
+        u32 rec = 0u, nt = 0u;
+        if (valid) {
+            rec = recs[idx];
+            const u32 root = parent[idx];
+            bool keep = false;
+            for (u32 i = 1u; i <= nroots; ++i) keep = keep || root == roots[i];
+            nt = keep ? (rec >> 17) & 7u : 0u;
+        }
+        // triangles kept in front of this record inside its segment: what earlier chunks left (s_tot) + the wave prefix since
+        // the segment's first record of this chunk
+        const u32 incl = sf_scan(nt), excl = incl - nt;
+        const int sprev = __builtin_amdgcn_update_dpp(-1, (int)lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const bool head = lane == 0 || sprev != (int)lo;
+        u32 hb = head ? excl + 1u : 0u;  // max-scan of (prefix at the head + 1): non-decreasing along the wave
+        {
+            u32 x = hb;
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)hb, 0x111, 0xf, 0xf, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)hb, 0x112, 0xf, 0xf, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)hb, 0x113, 0xf, 0xf, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+            x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+            hb = x - 1u;
+        }
+        const u32 carry = s_tot[w][lo];
+        const u32 tpre = carry + (excl - hb);
+        if (valid) recs[idx] = (rec & 0x1FFFFu) | (nt << 17) | (tpre << 20);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the last record of each segment run of this chunk leaves the segment's new total
+        const int snext = __builtin_amdgcn_update_dpp(-1, (int)lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        if (valid && (lane == 63 || snext != (int)lo || r + 1u >= nrec)) s_tot[w][lo] = tpre + nt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    segcb[seg] = make_uint2(tris | (act << 16), cb.y);
-    atomicAdd(&grpsum[seg >> 6], (u64)tris | ((u64)act << 32));
+    const u32 tris = act ? s_tot[w][lane] : 0u;
+    if (seg < nseg && act) segcb[seg] = make_uint2(tris | (act << 16), cb.y);
+    const u32 gt = sf_scan(tris);
+    if (lane == 63) atomicAdd(&grpsum[group], (u64)gt | ((u64)nrec << 32));
 }

@@ -5,6 +5,14 @@
  * the reference repository (Source/...).  Build with -ffp-contract=off and
  * without -ffast-math: the reference is x86-64 SSE code with one rounding per
  * float operation.
+ *
+ * PINNING.  By reference-held material: the case tables (the reference's marching_lookup.h compiled in place,
+ * oracle/check_tables_ref.c: 0 mismatches) and the tokenizer (the reference's own 9 self-test cases,
+ * evaluator.h:67-77).  NUMERIC RESULTS: PARITY UNPINNED -- the reference holds no numeric fixture, and its two
+ * hot-path translation units cannot be built here (both include <windows.h>; stand-in headers are not allowed).  The
+ * numeric pins this oracle passes (tests/test_oracle_pins.py: codes / soup fingerprints and counts of SURVEY.md
+ * section 4) were recorded by the survey session from a build of the unmodified sources that did use a stand-in
+ * windows.h; they are evidence, not a pin the tier rules accept.  DESIGN.md section 5.
  */
 #include "../include/mc_trig.h"
 #include "mc_oracle.h"

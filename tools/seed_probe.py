@@ -1,7 +1,8 @@
 """Developer probe: wall time of a seed-mode sweep against the dense sweep."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mc_amd as mc
 c = mc.Context(0)
 for n in (32, 256, 1024):
