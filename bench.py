@@ -224,8 +224,8 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)    # (a sweep is < 0.5 ms: 100 steps keep the pipeline's fill and drain
+    ap.add_argument("--warmup", type=int, default=10)    # below 2 % of the timed region; the whole run is the CPU baseline's 12 s)
     ap.add_argument("--grid-res", type=int, default=1024)
     ap.add_argument("--equation", default="x^2+y^2+z^2-1")
     ap.add_argument("--workload", choices=["sphere", "gyroid", "torus"], default="sphere",
