@@ -236,3 +236,32 @@ def test_random_trig_expressions_match_the_oracle(mc, orc, ext, seed):
         assert ((_u32(v) == _u32(o.soup)) | (np.isnan(v) & np.isnan(o.soup))).all(), eq
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_extensions_pinned_per_context(mc, orc):
+    """mc_context_set_extensions: one context accepts sin / cos whatever the process-wide word says, its neighbour on the
+    same device keeps the reference's grammar; ext < 0 returns a context to following the process-wide setting."""
+    assert mc.set_extensions(0) == 0                   # process-wide: the reference's grammar
+    a, b = mc.Context(0), mc.Context(0)
+    try:
+        a.set_extensions(mc.EXT_TRIG)
+        eq, step = "sin(x)+y", 0.25
+        r = a.march(eq, step)
+        old = orc.set_extensions(1)
+        try:
+            o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=3)
+        finally:
+            orc.set_extensions(old)
+        assert r.n_tris == o.n_tris > 0 and np.array_equal(r.codes(), o.codes)
+        with pytest.raises(mc.McError) as e:
+            b.march(eq, step)                           # the neighbour: letters other than x, y, z are rejected (evaluator.cpp:224)
+        assert e.value.code == mc.MC_ERR_PARSE
+        a.set_extensions(-1)
+        with pytest.raises(mc.McError):
+            a.march("cos(x)+y", step)
+        assert a.march("x+y", step).n_tris > 0          # both still sweep the reference's language
+    finally:
+        a.close()
+        b.close()
+        mc.set_extensions(0)
