@@ -334,6 +334,24 @@ __device__ __forceinline__ void cc_union(u32* parent, u32 a, u32 b) {
         if (atomicCAS(&parent[a], a, b) == a) return;
     }
 }
+// Most unions the link pass still attempts join two records that are in one set already.  That can be seen with PLAIN loads
+// (L1 / L2 hits instead of device-scope loads at ~1 us apiece): whatever such a load returns is an ancestor -- an out-of-date
+// one at worst -- and two records with a common ancestor are in one set, for good (sets only merge).  Only when the
+// ancestors differ is the exact, device-scope union made, starting from them.
+__device__ __forceinline__ void cc_union_fast(u32* parent, u32 a, u32 b) {
+    const u32* pl = parent;
+    for (;;) {
+        const u32 pa = pl[a];
+        if (pa == a) break;
+        a = pa;
+    }
+    for (;;) {
+        const u32 pb = pl[b];
+        if (pb == b) break;
+        b = pb;
+    }
+    if (a != b) cc_union(parent, a, b);
+}
 // index of the record of cell `cellx` of segment seg (records of a segment ascend in cellx), ~0u when it has none
 __device__ __forceinline__ u32 cc_lookup(const u32* __restrict__ recs, const uint2* __restrict__ segcb, u32 seg, u32 cellx) {
     const uint2 cb = segcb[seg];
@@ -559,8 +577,15 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         const u32 r = s_first[w][sg] + (k - off[sg]);
         if (mode == 2) {
             if (valid) {
-                const u32 root = cc_find_ro(parent, r);  // (roots are final: mode 1 has completed)
-                __hip_atomic_store(&parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (roots are final: mode 1 has completed, in the launch before.  Plain loads: whatever this launch has
+                // already overwritten with a root reads as that root or as the older link, and both lead to the root)
+                u32 root = r;
+                for (;;) {
+                    const u32 pp = ((const u32*)parent)[root];
+                    if (pp == root) break;
+                    root = pp;
+                }
+                parent[r] = root;
             }
             continue;  // wave-uniform
         }
@@ -584,16 +609,19 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         cc_lookup2(recs, segcb, wy, seg + (u32)nchunk, wz, seg + (u32)nchunk * (u32)n1, cellx, ry, rz);
         // parents, for the test above (any value read is an ancestor; equal ancestors = one set)
         const u32 none = 0xFFFFFFFFu;
-        const u32 pm = valid ? __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
-        const u32 px = rx != none ? __hip_atomic_load(&parent[rx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
-        const u32 py = ry != none ? __hip_atomic_load(&parent[ry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
-        const u32 pz = rz != none ? __hip_atomic_load(&parent[rz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        // (plain loads: a value that is out of date is still an ancestor -- mc_cc_local's, from the launch before, or a
+        // later one -- and the test only ever PRUNES a union when two ancestors are equal, i.e. the sets were one already)
+        const u32* __restrict__ pplain = parent;
+        const u32 pm = valid ? pplain[r] : none;
+        const u32 px = rx != none ? pplain[rx] : none;
+        const u32 py = ry != none ? pplain[ry] : none;
+        const u32 pz = rz != none ? pplain[rz] : none;
         const bool ux = cc_leader(s_tab[w], s_key[w], lane, rx != none, pm, px);
         const bool uy = cc_leader(s_tab[w], s_key[w], lane, ry != none, pm, py);
         const bool uz = cc_leader(s_tab[w], s_key[w], lane, rz != none, pm, pz);
-        if (ux) cc_union(parent, r, rx);
-        if (uy) cc_union(parent, r, ry);
-        if (uz) cc_union(parent, r, rz);
+        if (ux) cc_union_fast(parent, r, rx);
+        if (uy) cc_union_fast(parent, r, ry);
+        if (uz) cc_union_fast(parent, r, rz);
     }
 }
 
