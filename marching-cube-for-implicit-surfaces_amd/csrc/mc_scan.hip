@@ -563,18 +563,35 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
     __shared__ u32 s_off[4][65];
     __shared__ u32 s_first[4][64];
     __shared__ u32 s_tab[4][128], s_key[4][128];
-    if (overflow[0] != 0u) return;
+    __shared__ u32 s_total[4], s_next[4];
+    if (overflow[0] != 0u) return;  // (the whole grid: uniform)
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u32 seg0 = (blockIdx.x * 4u + w) * 64u;
-    if (seg0 >= nseg) return;  // whole wave
-    const u32* const off = s_off[w];
-    const u32 total = cc_group(segcb, seg0, nseg, lane, s_off[w], s_first[w]);
+    {
+        const u32 seg0w = (blockIdx.x * 4u + w) * 64u;
+        const u32 tot = seg0w < nseg ? cc_group(segcb, seg0w, nseg, lane, s_off[w], s_first[w]) : 0u;
+        if (lane == 0u) {
+            s_total[w] = tot;
+            s_next[w] = 0u;
+        }
+    }
+    __syncthreads();
+    // the waves of a workgroup share the chunks of its four groups (an LDS counter per group; own group first): groups
+    // differ in size by 10x and every chunk is a chain of dependent look-ups -- see mc_emit_direct (mc_kernels.hip)
+    for (u32 dw = 0u; dw < 4u; ++dw) {
+    const u32 wv = (w + dw) & 3u;
+    const u32 seg0 = (blockIdx.x * 4u + wv) * 64u;
+    const u32* const off = s_off[wv];
+    const u32 total = s_total[wv];
     const bool single = total <= CC_WIN;
-    for (u32 base = 0u; base < total; base += 64u) {  // (wave-uniform trip count: the shuffles below see every lane)
+    for (;;) {  // (wave-uniform trip count: the shuffles below see every lane)
+        u32 base = 0u;
+        if (lane == 0u) base = __hip_atomic_fetch_add(&s_next[wv], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= total) break;
         const u32 k = base + lane;
         const bool valid = k < total;
         const u32 sg = valid ? cc_segment_of(off, k) : 0u;
-        const u32 r = s_first[w][sg] + (k - off[sg]);
+        const u32 r = s_first[wv][sg] + (k - off[sg]);
         if (mode == 2) {
             if (valid) {
                 // (roots are final: mode 1 has completed, in the launch before.  Plain loads: whatever this launch has
@@ -622,6 +639,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         if (ux) cc_union_fast(parent, r, rx);
         if (uy) cc_union_fast(parent, r, ry);
         if (uz) cc_union_fast(parent, r, rz);
+    }
     }
 }
 
