@@ -152,8 +152,9 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     ctx = ctxs[0]
     frames = max(args.steps, 2)
     isos = np.linspace(-0.7, -0.1, frames).astype(np.float32)
+    t63 = mc_amd.FLAG_TILE63 if os.environ.get("MC_FORCE63") == "63" else 0   # developer A/B
     for c in ctxs:                                 # -0.4 has the most triangles: sizes the vertex buffers
-        c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING)
+        c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING | t63)
 
     def play(frame_isos, depth=depth):
         """Frame k goes to context k % depth (its own buffers and stream), so `depth` frames are in flight; EVERY frame's
@@ -183,7 +184,7 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     dt1 = time.perf_counter() - t1
     assert tris1 == tris
     # per-kernel times: the same frames once more, one at a time, from a capture that carries the hipEvent nodes
-    ctx.graph_build(eq, step, iso=-0.4)
+    ctx.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | t63)
     kt = np.zeros(4)
     for iso in isos:
         r = ctx.graph_replay(float(iso))
@@ -297,6 +298,8 @@ def main():
     if args.slab_of > 1 and world == 1:
         zb, ze = mc_amd.shard_layers(n1, args.slab_of, args.slab_of // 2)
     flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
+    if os.environ.get("MC_FORCE63") == "63":     # developer A/B: 63-row classify tiles whatever the grid size
+        flags |= mc_amd.FLAG_TILE63
     ctx = mc_amd.Context(local_rank)
     cdev = "cuda" if (multi and dist.get_backend() == "nccl") else "cpu"
     counts_dev = torch.zeros(world, dtype=torch.int64, device=cdev) if multi else None

@@ -66,6 +66,8 @@ enum {
                                /* on its own (the default for cheap f) ...                             */
     MC_FLAG_EMIT_SHARED = 512u,/* ... or the one that computes each lattice-edge vertex once per chunk */
                                /* of cells (the default for expensive f); the output must not change   */
+    MC_FLAG_TILE63 = 2048u,    /* diagnostic: classify with 63-row tiles whatever the grid size (small  */
+                               /* grids get shorter tiles by default); the output must not change       */
     MC_FLAG_SEAM = 1024u       /* with MC_FLAG_INDEXED on a Z slab: weld the slab as a PART OF THE WHOLE     */
                                /* GRID, so that the slabs' vertex_list / tri_list, concatenated in slab order, */
                                /* are the single sweep's Poly_Data bit for bit (see mc_index_rebase)          */

@@ -47,8 +47,12 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
         assert not d.size or np.nanmax(d) <= TOL_NRM, f"normals differ by {np.nanmax(d)}"
     # both emit kernels (mc_emit_direct, the default for cheap f; mc_emit, which shares vertices inside a chunk, the default
     # for expensive f) must write the same bytes
-    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED):
-        v2 = ctx.march(eq, step, iso, scale, flags | force, z[0], z[1]).vertices()
+    # ... and so must 63-row classify tiles (small grids get shorter ones by default)
+    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED, mc.FLAG_TILE63):
+        r2 = ctx.march(eq, step, iso, scale, flags | force, z[0], z[1])
+        if force == mc.FLAG_TILE63:
+            assert np.array_equal(r2.codes(), o.codes), "cube codes differ with 63-row tiles"
+        v2 = r2.vertices()
         assert np.array_equal(u32(v2[:, :, :3]), u32(v[:, :, :3])), f"positions differ with emit flag {force}"
         if flags & mc.FLAG_NORMALS:
             ok = ~(np.isnan(v2[:, :, 3:]) & np.isnan(v[:, :, 3:]))
