@@ -76,3 +76,55 @@ def test_oracle_calculate_normal(orc):
     m = orc.march_indexed(EQ["sphere"], step_of(24))
     assert np.abs(np.linalg.norm(m.normals, axis=1) - 1).max() < 1e-6
     assert (np.sum(m.normals * m.vertices, axis=1) > 0.9).all()
+
+
+def seam_slab_by_keys(eq, step, iso, scale, cons, zb, ze, n1):
+    """What MC_FLAG_INDEXED | MC_FLAG_SEAM specifies for the slab [zb, ze) (include/mc_hip.h: mc_index_rebase), stated with
+    the dictionary walk: weld the slab together with one ghost layer above and TWO below (the second one only so that the
+    first ghost layer's own ownership comes out as in the whole grid; the device gets that from lattice indices instead),
+    then hand out the slab's own triangles and the vertices its cells own, tri_list relative to the first own vertex
+    (a vertex of the slab below: negative)."""
+    lo, hi = max(zb - 2, 0), min(ze + 1, n1)
+    sw = wm.Sweep(eq, step, iso, (scale,) * 3, constraints=cons, z_begin=lo, z_end=hi)
+    v, t, first = sw.weld_by_keys()
+    owner_layer = np.empty(len(v), np.int64)
+    for _, (idx, cell, _e) in first.items():
+        owner_layer[idx] = cell[2]
+    # triangles in sweep order with their cell's layer
+    tri_layer = []
+    for cell in sorted(sw.cells, key=lambda c: (c[2], c[1], c[0])):
+        tri_layer += [cell[2]] * len(sw.cells[cell]["tris"])
+    tri_layer = np.array(tri_layer, np.int64)
+    keep_v = (owner_layer >= zb) & (owner_layer < ze)
+    keep_t = (tri_layer >= zb) & (tri_layer < ze)
+    assert not len(v) or (np.diff(np.flatnonzero(keep_v)) == 1).all()      # contiguous: everything is in sweep order
+    v0 = int(np.flatnonzero(keep_v)[0]) if keep_v.any() else int((owner_layer < zb).sum())
+    return v[keep_v], t[keep_t].astype(np.int64) - v0
+
+
+SEAM_SPEC_CASES = [
+    (EQ["sphere"], 16, 0.0, 1.0, (), [0, 5, 6, 11, 17]),
+    ("x+y", 12, 0.0, 1.0, (), [0, 4, 9, 13]),                                   # corner keys on every seam
+    ("x*y*z", 10, 0.0, 1.0, (), [0, 5, 6, 11]),
+    ("z", 6, 0.0, 1.0, (), [0, 3, 4, 7]),                                        # the surface is a seam plane
+    (EQ["sphere"], 16, 0.0, 1.0, (("z", ">", 0.02), ("x", ">", -0.5)), [0, 8, 9, 17]),
+    (EQ["goursat"], 16, -0.4, 1.0, (), [0, 6, 12, 17]),
+]
+
+
+@pytest.mark.parametrize("eq,n,iso,scale,cons,bounds", SEAM_SPEC_CASES)
+def test_seam_rule_slabs_concatenate_to_the_std_set_of_the_whole_grid(orc, eq, n, iso, scale, cons, bounds):
+    """The rule behind MC_FLAG_SEAM, on the CPU: slabs welded with ghost layers, cut back and re-based by the running vertex
+    count concatenate to the reference's std::set welding of the WHOLE grid (oracle replay), bit for bit."""
+    step = step_of(n)
+    ref = orc.march_indexed(eq, step, iso, (scale,) * 3, pow_mode=orc.POW_EXACT, constraints=cons)
+    n1 = bounds[-1]
+    vs, ts, off = [], [], 0
+    for zb, ze in zip(bounds[:-1], bounds[1:]):
+        v, t = seam_slab_by_keys(eq, step, iso, scale, cons, zb, ze, n1)
+        vs.append(v)
+        ts.append(t + off)                      # mc_index_rebase(offset)
+        off += len(v)
+    V, T = np.concatenate(vs), np.concatenate(ts)
+    assert V.shape == ref.vertices.shape and np.array_equal(V.view(np.uint32), ref.vertices.view(np.uint32))
+    assert np.array_equal(T.astype(np.uint32), ref.tris)
