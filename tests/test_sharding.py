@@ -39,6 +39,53 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_SEAM = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle"); sys.path.insert(0, sys.argv[1] + "/tests")
+import mc_amd, pyoracle as orc
+from test_weld_model import seam_slab_by_keys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(16))
+n1 = mc_amd.cells_per_axis(step)
+zb, ze = mc_amd.shard_layers(n1, world, rank)
+# what the rank's GPU does with MC_FLAG_INDEXED | MC_FLAG_SEAM, stated by the CPU model of the rule (tests/test_weld_model.py)
+v, t = seam_slab_by_keys(eq, step, 0.0, 1.0, (), zb, ze, n1)
+counts = torch.zeros(2 * world, dtype=torch.int64)
+dist.all_gather_into_tensor(counts, torch.tensor([len(v), len(t)], dtype=torch.int64))   # the one exchange: the counts
+voff, vtot = mc_amd.exclusive_offsets(counts[0::2].tolist())
+toff, ttot = mc_amd.exclusive_offsets(counts[1::2].tolist())
+t = t + voff[rank]                                              # mc_index_rebase(ctx, offset)
+V = torch.zeros(vtot * 3, dtype=torch.float32); T = torch.zeros(ttot * 3, dtype=torch.int64)
+V[voff[rank] * 3:(voff[rank] + len(v)) * 3] = torch.from_numpy(np.ascontiguousarray(v).reshape(-1))
+T[toff[rank] * 3:(toff[rank] + len(t)) * 3] = torch.from_numpy(np.ascontiguousarray(t).reshape(-1))
+dist.all_reduce(V); dist.all_reduce(T)                          # disjoint ranges: a sum is a concatenation
+if rank == 0:
+    ref = orc.march_indexed(eq, step, pow_mode=orc.POW_EXACT)   # the reference's std::set welding of the WHOLE grid
+    assert (vtot, ttot) == (ref.n_verts, ref.n_tris), (vtot, ttot, ref.n_verts, ref.n_tris)
+    assert np.array_equal(V.numpy().view(np.uint32), ref.vertices.reshape(-1).view(np.uint32))
+    assert np.array_equal(T.numpy().astype(np.uint32), ref.tris.reshape(-1))
+    print("SEAM_OK", vtot, ttot, voff)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_one_poly_data_from_two_slabs(tmp_path):
+    """world_size 2 on CPU: each rank welds its slab as a part of the whole grid (the MC_FLAG_SEAM rule, CPU model), the
+    ranks all-gather their vertex / triangle counts, re-base their tri_list by the offset (mc_index_rebase) and the
+    concatenation is the reference's Poly_Data of the whole grid, bit for bit."""
+    script = tmp_path / "worker_seam.py"
+    script.write_text(WORKER_SEAM)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29537", str(script), str(ROOT)], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "SEAM_OK" in r.stdout
+
+
 def test_shard_layers_cover_and_order(mc):
     for n in (1, 5, 33, 257, 1025, 2001):
         for world in (1, 2, 3, 4, 8):
