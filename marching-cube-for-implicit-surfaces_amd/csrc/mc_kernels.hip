@@ -1716,13 +1716,13 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
 
 // mc_emit_direct -- the emit kernel for CHEAP f (mc_runtime picks it when f costs less than the bookkeeping that
 // sharing a vertex between its ~6 output copies needs: measured).
-// One wave = one GROUP of 64 consecutive segments.  Phase 1, one lane per RECORD (= active
-// cell, written by mc_classify): find the owning segment by binary search over the group's
-// active-cell offsets (LDS), read the record, and expand its triangles into 4-byte work items
-// in LDS -- the list index is the triangle's position in the reference's emission order.
-// Phase 2, one lane per output VERTEX: edge lookup (nibble-packed table row in LDS), two corner
-// evaluations, the interpolation, the central-difference gradient of f for the normal, 24-byte
-// store.
+// A workgroup = 8 consecutive GROUPS of 64 segments; the unit of work is a CHUNK of 64 records of one of them, taken by
+// whichever wave is free (an LDS counter per group; a wave serves its own group first -- see the comment at the barrier
+// below).  Phase 1, one lane per RECORD (= active cell, written by mc_classify): find the owning segment by binary search
+// over the group's active-cell offsets (LDS), read the record, and expand its triangles into 4-byte work items in LDS --
+// the list index is the triangle's position in the reference's emission order.  Phase 2, one lane per output VERTEX: edge
+// lookup (nibble-packed table row in LDS), two corner evaluations, the interpolation, the central-difference gradient of f
+// for the normal, 24-byte store.
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                      float* __restrict__ verts) {
