@@ -678,9 +678,10 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // the wave index is wave-uniform, but the compiler only knows that if told: without the
     // readfirstlane every tile coordinate (and the whole walk's scalar algebra) lands in VGPRs
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long tile = (long long)blockIdx.x * MC_WPB_C + w;
-    const long long ntiles_main = (long long)p.nchunk_main * p.ntile_y * p.nz;
-    const long long ntiles = ntiles_main + (long long)p.ntile_t * p.nz;
+    // (tile numbers fit 32 bits -- the grid size does -- and 32-bit divisions are a third of the scalar code of 64-bit ones)
+    const u32 tile = blockIdx.x * (u32)MC_WPB_C + (u32)w;
+    const u32 ntiles_main = (u32)p.nchunk_main * (u32)p.ntile_y * (u32)p.nz;
+    const u32 ntiles = ntiles_main + (u32)p.ntile_t * (u32)p.nz;
     if (tile >= ntiles) return;  // whole wave
     const bool is_tail = tile >= ntiles_main;  // wave-uniform
     const int n1 = p.n1;
@@ -688,17 +689,17 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // (chunk fastest: the 4 waves of a workgroup cover 1 KB of each code row together.  Layer-fastest, which
     // gives the 4 waves equal work, measured the same: 0.380 vs 0.378 ms.)
     if (!is_tail) {
-        ch = (int)(tile % p.nchunk_main);
-        const long long t2 = tile / p.nchunk_main;
-        ty = (int)(t2 % p.ntile_y);
-        lz = (int)(t2 / p.ntile_y);
+        const u32 t2 = tile / (u32)p.nchunk_main;
+        ch = (int)(tile - t2 * (u32)p.nchunk_main);
+        lz = (int)(t2 / (u32)p.ntile_y);
+        ty = (int)(t2 - (u32)lz * (u32)p.ntile_y);
         y0 = ty * p.tile_h;
         ny = min(p.tile_h, n1 - y0);
     } else {  // tail tile: the last chunk's 1..4 cells of 64 consecutive rows, one row per lane
-        const long long tt = tile - ntiles_main;
+        const u32 tt = tile - ntiles_main;
         ch = p.nchunk - 1;
-        ty = (int)(tt % p.ntile_t);
-        lz = (int)(tt / p.ntile_t);
+        lz = (int)(tt / (u32)p.ntile_t);
+        ty = (int)(tt - (u32)lz * (u32)p.ntile_t);
         y0 = ty * 64;
         ny = min(64, n1 - y0);
     }
