@@ -434,6 +434,18 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
     const u32 off = incl - cnt;
     u8* __restrict__ tilebase = codes + ((u64)t.lz * n1 + t.y0) * p.pitch;
     u64 pend = rowPend;
+    // the dwordx4 stores of 4 pending rows at once: this lane's row of the group, the lane its 16-byte piece starts at, the
+    // valid bytes of the 4 dwords of the piece, and its byte offset inside the group (pieces beyond the row pitch get an
+    // offset the range check rejects)
+    const int q4 = t.lane & 3, k4 = t.lane & ~3;
+    u32 vm4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int xi = t.ch * MC_SEG + (k4 + i) * 4;
+        vm4[i] = (xi + 3 < n1) ? 0xFFFFFFFFu : (xi + 2 < n1) ? 0x00FFFFFFu : (xi + 1 < n1) ? 0x0000FFFFu : (xi < n1) ? 0x000000FFu : 0u;
+    }
+    const u32 xbyte4 = (u32)(t.ch * MC_SEG + k4 * 4);
+    const u32 woff4 = (xbyte4 < (u32)p.pitch) ? (u32)q4 * (u32)p.pitch + xbyte4 : 0x80000000u;
     u32 e0 = 0;
     u32 nbuf = 0;          // records waiting in recbuf
     u64 epochRows = 0ull;  // rows whose records are in recbuf
@@ -608,7 +620,26 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             // (Measured: 0.264 ms against 0.283 for gathering each row's listed dwords with ds_bpermute before its
             // store; but 0.296 when the rows were stored by the walk, microseconds earlier -- by then a line may have
             // left L2 and the late dword becomes a read-modify-write in HBM.)
-            u64 f = fit;
+            // Aligned groups of 4 such rows go out with ONE dwordx4 store (lane 4k+s writes the 16 bytes of lanes 4k..4k+3 of
+            // row j+s, as the walk stores its culled rows): the stores are bound by their NUMBER -- about 34 cycles of the
+            // CU's address unit each -- and the pending rows, one dword store per row, were 58 % of the kernel's stores
+            // (1.57 M of 2.69 M per 1025^3 sweep).
+            u64 g4 = fit & (fit >> 1) & (fit >> 2) & (fit >> 3) & 0x1111111111111111ull;
+            u64 f = fit & ~(g4 | (g4 << 1) | (g4 << 2) | (g4 << 3));
+            while (g4) {
+                const int jr = __builtin_ctzll(g4);
+                g4 &= g4 - 1ull;
+                const u32 alo = (u32)__shfl((int)rm.alllo, jr + q4, 64), ahi = (u32)__shfl((int)rm.allhi, jr + q4, 64);
+                const u32 bits = ((k4 & 32) ? ahi : alo) >> (k4 & 31);
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 v;
+                v.x = (bits & 1u) ? vm4[0] : 0u;
+                v.y = (bits & 2u) ? vm4[1] : 0u;
+                v.z = (bits & 4u) ? vm4[2] : 0u;
+                v.w = (bits & 8u) ? vm4[3] : 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)jr * (u32)p.pitch), 0, (int)(4u * (u32)p.pitch), 0x00020000), woff4, 0, 0);
+            }
             while (f) {
                 const int jr = __builtin_ctzll(f);
                 f &= f - 1ull;
@@ -971,6 +1002,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         asm volatile("" ::"v"(lxl), "v"(lxh), "v"(yv));
         const u64 rowsValid = (1ull << ny) - 1ull;  // ny <= 63 here
         const u64 cull = rowCull & rowsValid;
+        // (A block level between the row test and the lane test -- one more evaluation over 8 x 8 boxes of 32 cells x 8 rows,
+        // rows of a block whose boxes are all decided stored like culled rows -- was built and measured: at 513^3 it decides
+        // 85 % of the tiles that the 256-cell-wide row boxes leave undecided without holding a surface cell, and takes 17 % off
+        // the SUM of the waves' lifetimes on equation_3 -- and nothing off the kernel's time, which is set by when the tiles
+        // that do hold the surface start and how long each of them runs.  Removed again.)
         // (1) aligned blocks of 4 culled rows
         u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
         const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
