@@ -354,6 +354,9 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY 
 #ifndef MC_CLASSIFY_MINW
 #define MC_CLASSIFY_MINW 1
 #endif
+#ifndef MC_BLOCK_MIN_ROWS
+#define MC_BLOCK_MIN_ROWS 8  // undecided rows a tile must have for the block-level evaluation (MC_BLOCK_LEVEL) to be worth one more
+#endif
 
 struct McTileCtx {
     int ch, y0, iz, lz, lane;
@@ -1001,19 +1004,55 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         // only when its culled rows are in memory -- compute + store time instead of the larger of the two)
         asm volatile("" ::"v"(lxl), "v"(lxh), "v"(yv));
         const u64 rowsValid = (1ull << ny) - 1ull;  // ny <= 63 here
-        const u64 cull = rowCull & rowsValid;
-        // (A block level between the row test and the lane test -- one more evaluation over 8 x 8 boxes of 32 cells x 8 rows,
-        // rows of a block whose boxes are all decided stored like culled rows -- was built and measured: at 513^3 it decides
-        // 85 % of the tiles that the 256-cell-wide row boxes leave undecided without holding a surface cell, and takes 17 % off
-        // the SUM of the waves' lifetimes on equation_3 -- and nothing off the kernel's time, which is set by when the tiles
-        // that do hold the surface start and how long each of them runs.  Removed again.)
-        // (1) aligned blocks of 4 culled rows
+        const u64 cullRow = rowCull & rowsValid;
+        // BLOCK level (MC_BLOCK_LEVEL: the host defines it for polynomials of higher degree, jit_source in mc_runtime.hip).  The row test
+        // looks at boxes 256 cells wide; an enclosure grows with its box, so on small grids and for f of higher degree it
+        // leaves whole tiles undecided that hold no cell of the surface (513^3: 42 % of the kernel's wave time on equation_3
+        // went into tiles whose lane-level evaluations then found nothing).  ONE more evaluation covers the tile with 8 x 8
+        // boxes of 32 cells x 8 rows (lane = box): a block of 8 rows whose 8 boxes are all decided is finished -- its rows
+        // are stored like culled rows, with the boxes' values -- and only the others take the lane-level evaluations.
+        // Exact like the rest: a box is decided only when the enclosure proves every sample of its cells on one side of
+        // iso.  What it buys (equation_3 513^3): 85 % of those tiles decided, 17 % off the SUM of the waves' lifetimes --
+        // nothing off the time of one sweep alone, which is set by the tiles that do hold the surface, but 7.5 % off the step
+        // with three sweeps in flight, whose kernels take the freed wave slots.  Cheap f gains nothing (sphere 513^3: +1.5 %).
+        // In a tile the staged enclosure (MC_IV_NY) handles, this evaluation is the plain mc_f_iv.
+        u64 rowBlk = 0ull;   // bit j: row j is decided by its block of 8 rows
+        u64 blkFull = 0ull;  // bit 8 * rb + cb: every sample of column block cb of row block rb is above iso
+#ifdef MC_BLOCK_LEVEL
+        if (__builtin_popcountll(rowsValid & ~cullRow) >= MC_BLOCK_MIN_ROWS) {
+            const int cb = lane & 7, rb = lane >> 3;
+            const float bxa = tl.xs[cb * 32], bxb = tl.xs[cb * 32 + 32];
+            const float bya = __shfl(yv, min(8 * rb, 63), 64), byb = __shfl(yv, min(8 * rb + 8, ny), 64);
+            float lo, hi;
+            mc_f_iv(__builtin_fminf(bxa, bxb), __builtin_fmaxf(bxa, bxb), __builtin_fminf(bya, byb), __builtin_fmaxf(bya, byb), zl, zh, lo, hi);
+            bool full = lo > iso, none = !(hi > iso);
+#ifdef MC_CONS
+            bool allok, dead;
+            mc_ok_iv(__builtin_fminf(bxa, bxb), __builtin_fmaxf(bxa, bxb), __builtin_fminf(bya, byb), __builtin_fmaxf(bya, byb), zl, zh, allok, dead);
+            full = full && allok;
+            none = none || dead;
+#endif
+            const bool outside = ch * MC_SEG + cb * 32 >= n1;  // the box holds no cell of the grid (ragged last chunk)
+            blkFull = __ballot(full && !outside);
+            u64 dec = __ballot(full || none || outside);
+            dec &= dec >> 4;
+            dec &= dec >> 2;
+            dec &= dec >> 1;
+            dec &= 0x0101010101010101ull;                   // bit 8 * rb: the 8 boxes of row block rb are all decided
+            rowBlk = ((dec << 8) - dec) & rowsValid & ~cullRow;  // ... spread over its rows 8 * rb .. 8 * rb + 7
+        }
+#endif
+        const u64 cull = cullRow | rowBlk;
+        const u32 lane8 = (u32)lane >> 3;
+        // (1) aligned blocks of 4 decided rows (they lie in one block of 8 rows)
         u64 m4 = cull & (cull >> 1) & (cull >> 2) & (cull >> 3) & 0x1111111111111111ull;
         const u64 blockRows = m4 | (m4 << 1) | (m4 << 2) | (m4 << 3);
         while (m4) {
             const int j = __builtin_ctzll(m4);
             m4 &= m4 - 1ull;
-            const u32 c = ((rowFull >> j) >> q) & 1ull ? 0xFFFFFFFFu : 0u;
+            const u32 rf4 = (u32)((rowFull & cullRow) >> j) & 0xFu, rb4 = (u32)(rowBlk >> j) & 0xFu;
+            const u32 patt = (u32)(blkFull >> (8 * (j >> 3))) & 0xFFu;
+            const u32 c = (((rf4 >> q) | ((rb4 >> q) & (patt >> lane8))) & 1u) ? 0xFFFFFFFFu : 0u;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             u32x4 v;
             v.x = c & vm4[0];
@@ -1023,12 +1062,14 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
             __builtin_amdgcn_raw_buffer_store_b128(
                 v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, wbytes, 0x00020000), woff, 0, MC_CULLED_STORE_AUX);
         }
-        // (2) the other culled rows
+        // (2) the other decided rows
         u64 m1 = cull & ~blockRows;
         while (m1) {
             const int j = __builtin_ctzll(m1);
             m1 &= m1 - 1ull;
-            const u32 v = ((rowFull >> j) & 1ull) ? vmask : 0u;
+            const u32 patt = (u32)(blkFull >> (8 * (j >> 3))) & 0xFFu;
+            const u32 on = (u32)((rowFull & cullRow) >> j) | ((u32)(rowBlk >> j) & (patt >> lane8));
+            const u32 v = (on & 1u) ? vmask : 0u;
             __builtin_amdgcn_raw_buffer_store_b32(
                 v, __builtin_amdgcn_make_buffer_rsrc(tilebase + (u64)((u32)j * (u32)p.pitch), 0, rowbytes, 0x00020000), xoff, 0, MC_CULLED_STORE_AUX);
         }
