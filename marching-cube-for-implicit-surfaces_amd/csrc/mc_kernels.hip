@@ -510,9 +510,14 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
             // the 20 lattice samples of the lane's 4 cells: same mc_f, same operands, same compare as
             // everywhere else (marching.cpp:475-479, :497-505)
             const float yl = tl.ys[jj], yu = tl.ys[jj + 1];
-            u32 sb = 0;  // bit (4*c + 2*r + pl): sample x0+c, row r (0 lower / 1 upper), plane pl
+            // Each sample's verdict goes STRAIGHT to the code bits it is: sample c (column x0+c), row r, plane pl is corner
+            // 0/4/3/7 (r, pl = 00/01/10/11) of cell c and corner 1/5/2/6 of cell c-1 (marching.cpp:471-472), i.e. ONE constant
+            // per sample with both bits at their places in the lane's code dword, OR-ed in when f > iso -- no code is ever
+            // assembled from sample bits (that was 72 of the ~430 vector instructions of a chunk).
+#define MC_SAMPLE_BITS(c_, asleft_, asright_) \
+    ((((c_) < 4) ? ((u32)(asleft_) << (8 * ((c_) & 3))) : 0u) | (((c_) > 0) ? ((u32)(asright_) << (8 * (((c_) + 3) & 3))) : 0u))
 #ifdef MC_CONS
-            u32 ob = 0;  // same layout: the sample is inside every enabled constraint (marching.cpp:255-280)
+            u32 ob = 0;  // bit (4*c + 2*r + pl): the sample is inside every enabled constraint (marching.cpp:255-280)
 #endif
 #ifdef MC_TAB
             float UYl[MC_TAB_NY], UYu[MC_TAB_NY];
@@ -525,19 +530,21 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 const float x = tl.xs[ln * 4 + c];
+                const u32 k00 = MC_SAMPLE_BITS(c, 0x01u, 0x02u), k01 = MC_SAMPLE_BITS(c, 0x10u, 0x20u);  // (lower row, plane z / z+1)
+                const u32 k10 = MC_SAMPLE_BITS(c, 0x08u, 0x04u), k11 = MC_SAMPLE_BITS(c, 0x80u, 0x40u);  // (upper row, plane z / z+1)
 #ifdef MC_TAB  // the same values mc_f would compute: its one-variable sub-expressions come from the tables
                 float UX[MC_TAB_NX];
 #pragma unroll
                 for (int k = 0; k < MC_TAB_NX; ++k) UX[k] = tl.tx[k * 264 + ln * 4 + c];
-                sb |= (mc_f_t(x, yl, zk, UX, UYl, tl.tz0) > iso ? 1u : 0u) << (4 * c + 0);
-                sb |= (mc_f_t(x, yl, zk1, UX, UYl, tl.tz1) > iso ? 1u : 0u) << (4 * c + 1);
-                sb |= (mc_f_t(x, yu, zk, UX, UYu, tl.tz0) > iso ? 1u : 0u) << (4 * c + 2);
-                sb |= (mc_f_t(x, yu, zk1, UX, UYu, tl.tz1) > iso ? 1u : 0u) << (4 * c + 3);
+                dw |= mc_f_t(x, yl, zk, UX, UYl, tl.tz0) > iso ? k00 : 0u;
+                dw |= mc_f_t(x, yl, zk1, UX, UYl, tl.tz1) > iso ? k01 : 0u;
+                dw |= mc_f_t(x, yu, zk, UX, UYu, tl.tz0) > iso ? k10 : 0u;
+                dw |= mc_f_t(x, yu, zk1, UX, UYu, tl.tz1) > iso ? k11 : 0u;
 #else
-                sb |= (mc_f(x, yl, zk) > iso ? 1u : 0u) << (4 * c + 0);
-                sb |= (mc_f(x, yl, zk1) > iso ? 1u : 0u) << (4 * c + 1);
-                sb |= (mc_f(x, yu, zk) > iso ? 1u : 0u) << (4 * c + 2);
-                sb |= (mc_f(x, yu, zk1) > iso ? 1u : 0u) << (4 * c + 3);
+                dw |= mc_f(x, yl, zk) > iso ? k00 : 0u;
+                dw |= mc_f(x, yl, zk1) > iso ? k01 : 0u;
+                dw |= mc_f(x, yu, zk) > iso ? k10 : 0u;
+                dw |= mc_f(x, yu, zk1) > iso ? k11 : 0u;
 #endif
 #ifdef MC_CONS
                 ob |= (mc_ok(x, yl, zk) ? 1u : 0u) << (4 * c + 0);
@@ -546,20 +553,20 @@ __device__ __forceinline__ u32 mc_backend(const McParams& p, const McTileCtx& t,
                 ob |= (mc_ok(x, yu, zk1) ? 1u : 0u) << (4 * c + 3);
 #endif
             }
-            // cube code bit i <-> corner i (marching.cpp:471-472): with s = nibble of sample c and
-            // n = nibble of sample c+1:  0:(x0,y0,z0)=s.0  1:(x1,y0,z0)=n.0  2:(x1,y1,z0)=n.2  3:(x0,y1,z0)=s.2
-            //                            4:(x0,y0,z1)=s.1  5:(x1,y0,z1)=n.1  6:(x1,y1,z1)=n.3  7:(x0,y1,z1)=s.3
+#undef MC_SAMPLE_BITS
+            {
+                // cells beyond the end of the grid (ragged last chunk) hold no code; with constraints, a cell with a corner
+                // outside one is skipped (marching.cpp:476): no triangles, code 0
+                u32 keep = 0u;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u32 sN = (sb >> (4 * c)) & 0xFu, nN = (sb >> (4 * c + 4)) & 0xFu;
-                const u32 code = (sN & 1u) | ((nN & 1u) << 1) | (((nN >> 2) & 1u) << 2) | (((sN >> 2) & 1u) << 3) |
-                                 (((sN >> 1) & 1u) << 4) | (((nN >> 1) & 1u) << 5) | (((nN >> 3) & 1u) << 6) |
-                                 (((sN >> 3) & 1u) << 7);
+                for (int c = 0; c < 4; ++c) {
+                    bool k = x0 + c < n1;
 #ifdef MC_CONS
-                // a cell with a corner outside a constraint is skipped (marching.cpp:476): no triangles, code 0
-                if (((ob >> (4 * c)) & 0xFFu) != 0xFFu) continue;
+                    k = k && ((ob >> (4 * c)) & 0xFFu) == 0xFFu;
 #endif
-                if (x0 + c < n1) dw |= code << (8 * c);
+                    keep |= k ? 0xFFu << (8 * c) : 0u;
+                }
+                dw &= keep;
             }
             if (!valid) dw = 0u;
             ej = jj;
