@@ -339,15 +339,20 @@ def main():
     # them into this step's slot and feeds the RCCL all-gather; the next sweep is ordered behind that copy (its scan
     # clears the counts).  Only the fence at the end of the timed region waits for anything.
     lib_streams = sides = totals_devs = slots = None
+    exchange_note = None
     if multi and cdev == "cuda" and not args.no_graph:
         def raw_totals(c):   # zero-copy view of a context's {n_tris, n_active} words (same address sweep after sweep)
             class _Raw:
                 __cuda_array_interface__ = {"shape": (2,), "typestr": "<i8", "data": (int(c.graph_replay(0.0).d_totals), False), "version": 2}
             return torch.as_tensor(_Raw(), device=f"cuda:{local_rank}")
-        totals_devs = [raw_totals(c) for c in ctxs]
-        lib_streams = [torch.cuda.ExternalStream(c.stream(), device=f"cuda:{local_rank}") for c in ctxs]
-        sides = [torch.cuda.Stream(device=f"cuda:{local_rank}") for _ in ctxs]
-        slots = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int64, device=cdev)
+        try:
+            totals_devs = [raw_totals(c) for c in ctxs]
+            lib_streams = [torch.cuda.ExternalStream(c.stream(), device=f"cuda:{local_rank}") for c in ctxs]
+            sides = [torch.cuda.Stream(device=f"cuda:{local_rank}") for _ in ctxs]
+            slots = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int64, device=cdev)
+        except Exception as e:  # noqa: BLE001 -- the exchange then goes through the host (below); the sweeps are the same
+            exchange_note = f"host (device-side set-up failed: {type(e).__name__}: {e})"[:200]
+            totals_devs = lib_streams = sides = slots = None
     step_no = [0]
 
     def one_step():
@@ -470,7 +475,7 @@ def main():
                        "in_flight": depth,
                        "ms_per_step_one_in_flight": round(serial_ms, 4) if serial_ms is not None else None,
                        "count_exchange": (None if not multi else "rccl all_gather_into_tensor, device-side counts" if totals_devs is not None
-                                          else "all_gather_into_tensor through the host"),
+                                          else (exchange_note or "all_gather_into_tensor through the host")),
                        "z_bounds": bounds if world > 1 else None},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
