@@ -347,10 +347,13 @@ __device__ __forceinline__ bool amb_flip(const McParams& p, int face, PX ux, PY 
 // sampling walk instead of 1-2: the previous row's samples stay in registers (2 evaluations per cell) and rows /
 // lanes are classified by a min/max tree over the lane's 8 new samples; the back-end is the same.
 //
-// What bounds it (measured): the 1.26 GB of stores at ~5 TB/s, with the instruction stream
-// (89 M vector + 69 M scalar wave-instructions per 1025^3 sweep) just below that.  Hence the rules kept throughout:
-// no global LOAD after the first store (vmcnt retires in order: a load would wait for every store in flight),
-// whole 128-byte lines only, wave-uniform work on the scalar unit only where it is cheaper than on the VALU.
+// What bounds it (measured; 1025^3 sphere: 1.21 GB of stores, 76 M vector + 67 M scalar
+// wave-instructions): no single unit.  Its waves wait for data 48 % of their time (half of that in the prologue, whose
+// loads queue behind the kernel's own stores), wait for their turn to issue 23 %, execute 30 %; the vector ALU is busy
+// 57 % -- all of it while back-ends run -- and the store path's FIFOs are full 1 % of the time.  It needs its 5 waves
+// per SIMD (4: +16 %) and gains nothing from 6.  The rules kept throughout: no global LOAD after the first store (vmcnt
+// retires in order: a load would wait for every store in flight), whole 128-byte lines only, as few store INSTRUCTIONS as
+// possible (dwordx4 over 4 rows), wave-uniform work on the scalar unit only where it is cheaper than on the VALU.
 #ifndef MC_CLASSIFY_MINW
 #define MC_CLASSIFY_MINW 1
 #endif
