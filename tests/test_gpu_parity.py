@@ -350,6 +350,13 @@ def test_torus_512_properties(mc, ctx):
     ("eq3", 512, 0.0, (300, 303)),
     ("goursat", 512, -0.4, (100, 103)),    # BASELINE config 5's surface
     ("goursat", 512, -0.7, (436, 439)),
+    # ragged last chunks (44 / 127 / 129 cells, and a 2-cell tail plane) under the block level of the interval walk, which
+    # these two staged polynomials take: boxes beyond the end of the grid, partly filled boxes
+    ("eq3", 299, 0.0, (148, 151)),
+    ("goursat", 300, -0.4, (60, 63)),
+    ("eq3", 382, 0.0, (190, 193)),
+    ("goursat", 640, -0.4, (100, 102)),
+    ("goursat", 257, -0.5, (128, 131)),
 ])
 def test_full_size_grids_thin_slabs_against_the_oracle(mc, orc, ctx, name, n, iso, z):
     """BASELINE's full-size grids, a few layers at a time (what the CPU oracle sweeps in seconds): cube codes and the
