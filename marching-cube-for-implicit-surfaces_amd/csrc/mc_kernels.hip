@@ -155,6 +155,10 @@ struct McParams {
     const u32* overflow;  // the overflow word for the kernels BEHIND the scan (the scan moves it into the sweep's totals and
                           // clears the allocator for the next sweep)
     const float* tab;     // MC_TAB: f's one-variable sub-expressions per lattice index (mc_tabulate), else unused
+    int nz_a;             // classify: the slab's first nz_a layers are cut into tiles of tile_h rows, the others -- the LAST tiles
+    int tile_h2;          // of the launch -- into tiles of tile_h2 <= tile_h rows: the waves that start last are the ones the
+    int ntile_y2;         // chip drains on, and a short tile is a short drain (nz_a == nz: one height).  ceil(n1 / tile_h2)
+    int pad2;
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
@@ -724,7 +728,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // (tile numbers fit 32 bits -- the grid size does -- and 32-bit divisions are a third of the scalar code of 64-bit ones)
     const u32 tile = blockIdx.x * (u32)MC_WPB_C + (u32)w;
-    const u32 ntiles_main = (u32)p.nchunk_main * (u32)p.ntile_y * (u32)p.nz;
+    const u32 ntiles_a = (u32)p.nchunk_main * (u32)p.ntile_y * (u32)p.nz_a;
+    const u32 ntiles_main = ntiles_a + (u32)p.nchunk_main * (u32)p.ntile_y2 * (u32)(p.nz - p.nz_a);
     const u32 ntiles = ntiles_main + (u32)p.ntile_t * (u32)p.nz;
     if (tile >= ntiles) return;  // whole wave
     const bool is_tail = tile >= ntiles_main;  // wave-uniform
@@ -733,12 +738,17 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // (chunk fastest: the 4 waves of a workgroup cover 1 KB of each code row together.  Layer-fastest, which
     // gives the 4 waves equal work, measured the same: 0.380 vs 0.378 ms.)
     if (!is_tail) {
-        const u32 t2 = tile / (u32)p.nchunk_main;
-        ch = (int)(tile - t2 * (u32)p.nchunk_main);
-        lz = (int)(t2 / (u32)p.ntile_y);
-        ty = (int)(t2 - (u32)lz * (u32)p.ntile_y);
-        y0 = ty * p.tile_h;
-        ny = min(p.tile_h, n1 - y0);
+        const bool late = tile >= ntiles_a;  // (wave-uniform) one of the short tiles of the slab's last layers
+        const u32 tr = late ? tile - ntiles_a : tile;
+        const u32 nty = (u32)(late ? p.ntile_y2 : p.ntile_y);
+        const int th = late ? p.tile_h2 : p.tile_h;
+        const u32 t2 = tr / (u32)p.nchunk_main;
+        ch = (int)(tr - t2 * (u32)p.nchunk_main);
+        const u32 lr = t2 / nty;
+        ty = (int)(t2 - lr * nty);
+        lz = (int)lr + (late ? p.nz_a : 0);
+        y0 = ty * th;
+        ny = min(th, n1 - y0);
     } else {  // tail tile: the last chunk's 1..4 cells of 64 consecutive rows, one row per lane
         const u32 tt = tile - ntiles_main;
         ch = p.nchunk - 1;
