@@ -158,7 +158,8 @@ struct McParams {
     int nz_a;             // classify: the slab's first nz_a layers are cut into tiles of tile_h rows, the others -- the LAST tiles
     int tile_h2;          // of the launch -- into tiles of tile_h2 <= tile_h rows: the waves that start last are the ones the
     int ntile_y2;         // chip drains on, and a short tile is a short drain (nz_a == nz: one height).  ceil(n1 / tile_h2)
-    int pad2;
+    int layer_order;      // classify: 0 = the layers in z order, 1 = from the slab's middle outwards (mc_runtime tries both and keeps
+                          // the faster one per equation and grid)
 };
 
 #define MC_SEG 256          // cells per segment (4 per lane)
@@ -746,7 +747,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         ch = (int)(tr - t2 * (u32)p.nchunk_main);
         const u32 lr = t2 / nty;
         ty = (int)(t2 - lr * nty);
-        lz = (int)lr + (late ? p.nz_a : 0);
+        // Launch order of the layers.  A launch ends when its longest waves do.  A surface that is closed inside the domain has
+        // its long tiles in the middle layers: started first they are the floor of the kernel's time, started in the middle of
+        // the launch (equation_3 513^3: at 13 us, 40 us long, in a kernel of 55) they are that plus their start -- so those
+        // sweeps run from the slab's middle outwards (mid, mid + 1, mid - 1, ...), the outer layers, short tiles, filling the
+        // end.  Where the heavy layers lie elsewhere (Goursat: +10 %) z order is better; the host measures both.
+        const int li = (int)lr + (late ? p.nz_a : 0), mid = (p.nz - 1) >> 1;
+        lz = p.layer_order == 0 ? li : (li & 1) ? mid + ((li + 1) >> 1) : mid - (li >> 1);
         y0 = ty * th;
         ny = min(th, n1 - y0);
     } else {  // tail tile: the last chunk's 1..4 cells of 64 consecutive rows, one row per lane
