@@ -327,6 +327,12 @@ def main():
     # 0.494 ms per 1025^3 sweep; three: 0.42; on a 1/8 slab 0.088 -> 0.061: tools/concurrent_probe2.py).
     depth = 1 if args.no_graph else max(1, args.in_flight)
     ctxs = [ctx] + [mc_amd.Context(local_rank) for _ in range(depth - 1)]
+    # several sweeps in flight: tell the library (FLAG_BATCH: it then chooses for throughput where that differs from the
+    # fastest single sweep -- mc_emit on small grids); the one-in-flight figure below is taken WITHOUT the flag, on a
+    # context of its own, as a caller that issues one march() at a time would run
+    lat_flags = flags
+    if depth > 1:
+        flags |= mc_amd.FLAG_BATCH
     r0 = None
     for c in ctxs:
         r0c = c.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)   # sizes every buffer; this rank's counts
@@ -409,14 +415,22 @@ def main():
 
     # the same K steps with ONE sweep in flight (context 0 alone, each sweep behind the previous one), for comparison
     serial_ms = None
+    ctx1 = None
     if not multi and not args.no_graph and depth > 1:
+        ctx1 = mc_amd.Context(local_rank)   # (its own buffers and capture, without FLAG_BATCH)
+        ctx1.march(eq, step, 0.0, scale, flags=lat_flags, z_begin=zb, z_end=ze)
+        ctx1.graph_build(eq, step, 0.0, scale, lat_flags | mc_amd.FLAG_NO_TIMING, zb, ze)
+        for _ in range(max(2, args.warmup)):
+            ctx1.graph_replay_async(0.0)
+        ctx1.graph_wait()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            ctx.graph_replay_async(0.0)
-        ctx.graph_wait()
+            ctx1.graph_replay_async(0.0)
+        ctx1.graph_wait()
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        ctx1.close()
 
     # per-kernel GPU times for the roofline: the same K sweeps again, replayed one by one from a capture that carries the
     # hipEvent nodes (events are read on the host, so these replays are synchronous; right behind the timed region, same

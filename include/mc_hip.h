@@ -68,9 +68,14 @@ enum {
                                /* of cells (the default for expensive f); the output must not change   */
     MC_FLAG_TILE63 = 2048u,    /* diagnostic: classify with 63-row tiles whatever the grid size (small  */
                                /* grids get shorter tiles by default); the output must not change       */
-    MC_FLAG_SEAM = 1024u       /* with MC_FLAG_INDEXED on a Z slab: weld the slab as a PART OF THE WHOLE     */
+    MC_FLAG_SEAM = 1024u,      /* with MC_FLAG_INDEXED on a Z slab: weld the slab as a PART OF THE WHOLE     */
                                /* GRID, so that the slabs' vertex_list / tri_list, concatenated in slab order, */
                                /* are the single sweep's Poly_Data bit for bit (see mc_index_rebase)          */
+    MC_FLAG_BATCH = 4096u      /* the caller keeps SEVERAL sweeps in flight (one context each): choose for     */
+                               /* throughput where that differs from the fastest single sweep -- on small grids */
+                               /* the emit kernel of an expensive f otherwise puts 4 waves on each group of     */
+                               /* cells, which shortens one sweep by 8-20 % and costs a batch 9 %.  The output  */
+                               /* does not change                                                              */
 };
 
 typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */

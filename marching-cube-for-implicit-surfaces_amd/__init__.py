@@ -22,6 +22,7 @@ LIB_PATH = _HERE / ("libmc_hip_dev.so" if os.environ.get("MC_AMD_DEV_LIB") == "1
 MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NOMEM, MC_ERR_OVERFLOW = range(8)
 FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_INDEXED, FLAG_NO_CULL, FLAG_NO_TIMING = 1, 2, 4, 8, 32, 64, 128
 FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED, FLAG_SEAM, FLAG_TILE63 = 256, 512, 1024, 2048
+FLAG_BATCH = 4096   # several sweeps in flight (one context each): choose for throughput where that differs from the fastest single sweep
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

@@ -1495,7 +1495,15 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // make wave-uniformity visible
     const u32 ngroups = (k.nseg + 63u) / 64u;
-    const u32 group = blockIdx.x * (u32)MC_WPB_ES + (u32)w;
+    // MC_ES_SAMEGROUP (small grids: mc_runtime): the workgroup's waves all serve ONE group and take its 64-record chunks in
+    // turn.  A group's chunks are a chain of dependent phases in one wave -- 4.6 us each -- and on a grid whose whole emit
+    // fits the chip at once the kernel is as long as the longest chain (equation_3 513^3: 2 423 waves, all started in
+    // the first microseconds, the longest 7 chunks = 35 of the kernel's 36 us).
+#ifdef MC_ES_SAMEGROUP
+    const u32 group = blockIdx.x, usub = (u32)w, ustep = 64u * (u32)MC_WPB_ES;
+#else
+    const u32 group = blockIdx.x * (u32)MC_WPB_ES + (u32)w, usub = 0u, ustep = 64u;
+#endif
     if (group >= ngroups) return;  // (the grid is rounded up to whole workgroups)
     // every load that does not depend on another is issued up front: the group's offsets, per-segment counts, the
     // overflow word and the two words of *P
@@ -1509,6 +1517,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
     const u32 cnt = seg < k.nseg ? cb.x : 0u;
     // rec_overflow: mc_classify ran out of record space (the host grows the buffer and sweeps again)
     if (g0.y == g1.y || rec_overflow != 0u) return;  // no active cell in these 64 segments
+    if (64u * usub >= g1.y - g0.y) return;            // (MC_ES_SAMEGROUP) fewer chunks than waves: nothing for this one
     McParams p;  // (mc_F reads the scale factors from it)
     p.sx = k.sx;
     p.sy = k.sy;
@@ -1563,9 +1572,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         }
         return lo;
     };
-    u32 lo = find_segment((u32)lane);
-    u32 rec = (u32)lane < nrec ? recs[rbase[lo] + ((u32)lane - actoff[lo])] : 0u;
-    for (u32 r0 = 0; r0 < nrec;) {
+    // (a wave's records come in units of 64: [ustart, uend); a unit is worked off in one chunk, or in several when it is cut)
+    u32 ustart = 64u * usub;
+    if (ustart >= nrec) return;
+    u32 uend = min(ustart + 64u, nrec);
+    u32 lo = find_segment(ustart + (u32)lane);
+    u32 rec = ustart + (u32)lane < nrec ? recs[rbase[lo] + (ustart + (u32)lane - actoff[lo])] : 0u;
+    for (u32 r0 = ustart; r0 < nrec;) {
         const u32 gtri0 = trioff[lo] + (rec >> 20);
         const u32 sr = segrec[lo];
         const u32 code = (rec >> 8) & 0xFFu;
@@ -1575,7 +1588,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         const u32 cm = crossed_edges(code);
 
         // ---- B. ownership inside the chunk; a chunk that would compute more than MC_VCAP vertices is cut in halves
-        u32 nvalid = min(64u, nrec - r0);
+        u32 nvalid = min(64u, uend - r0);
         u32 S, sb, M, vx, vy, vxy, ny_lane;
         for (;;) {
             const bool valid = (u32)lane < nvalid;
@@ -1664,7 +1677,13 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         // The next chunk's records are fetched NOW: vmcnt retires in order, so a load issued behind this chunk's vertex
         // stores (phase D) would wait until they have all landed; issued here its latency hides under phase C, and the
         // wait for it in front of D finds the previous chunk's stores long gone.
-        const u32 rn = r0 + nvalid + (u32)lane;
+        u32 r0_n = r0 + nvalid;  // the rest of this unit, or this wave's next unit
+        if (r0_n >= uend) {
+            ustart += ustep;
+            r0_n = ustart;
+            uend = min(ustart + 64u, nrec);
+        }
+        const u32 rn = r0_n + (u32)lane;
         const u32 lo_n = find_segment(rn);
         u32 rec_n = 0u;
         if (rn < nrec) rec_n = recs[rbase[lo_n] + (rn - actoff[lo_n])];
@@ -1780,7 +1799,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        r0 += nvalid;
+        r0 = r0_n;
         lo = lo_n;
         rec = rec_n;
     }

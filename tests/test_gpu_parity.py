@@ -48,7 +48,8 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
     # both emit kernels (mc_emit_direct, the default for cheap f; mc_emit, which shares vertices inside a chunk, the default
     # for expensive f) must write the same bytes
     # ... and so must 63-row classify tiles (small grids get shorter ones by default)
-    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED, mc.FLAG_TILE63):
+    # ... and mc_emit with its waves one per group (FLAG_BATCH) or four per group (an expensive f on a small grid)
+    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED, mc.FLAG_EMIT_SHARED | mc.FLAG_BATCH, mc.FLAG_TILE63):
         r2 = ctx.march(eq, step, iso, scale, flags | force, z[0], z[1])
         if force == mc.FLAG_TILE63:
             assert np.array_equal(r2.codes(), o.codes), "cube codes differ with 63-row tiles"

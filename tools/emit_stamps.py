@@ -21,6 +21,8 @@ eq, scale = "x^2+y^2+z^2-1", (1.0,) * 3
 if "--workload" in sys.argv and sys.argv[sys.argv.index("--workload") + 1] == "gyroid":
     mc_amd.set_extensions(1)
     eq, scale = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)", (12.566371,) * 3
+if "--workload" in sys.argv and sys.argv[sys.argv.index("--workload") + 1] == "torus":
+    eq = "(x^2+y^2+z^2+(1/3)^2-(1/5)^2)^2-4*((1/2)*x-(2.36/6)*(1/5))^2-4*(1/3)^2*y^2"
 ctx = mc_amd.Context(0)
 step = float(np.float32(2.0) / np.float32(n))
 L = mc_amd.lib()
