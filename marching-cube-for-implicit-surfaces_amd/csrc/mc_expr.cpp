@@ -2,6 +2,7 @@
 #include "mc_expr.hpp"
 
 #include "mc_trig.h"
+#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -448,6 +449,58 @@ std::string emit_hip_tabulated(const Program& p, int min_cost) {
         if (!need[i] || is_h[i]) continue;
         if (p.nodes[i].a >= 0) need[p.nodes[i].a] = 1;
         if (p.nodes[i].b >= 0) need[p.nodes[i].b] = 1;
+    }
+    // MC_TAB_SYM: the three axes' lists hold the SAME functions of their variable (gyroid: {sin, cos} each), possibly in
+    // another order: mc_f_ux(t, C) then serves any axis -- mc_tab_sym_y / _z put C into that axis' order -- and mc_emit can
+    // compute the vertices of all three edge directions in one pass instead of one pass per axis (mc_emit_sym).
+    {
+        std::function<std::string(int)> canon = [&](int i) -> std::string {
+            const Node& nd = p.nodes[i];
+            if (nd.op == NodeOp::VARX || nd.op == NodeOp::VARY || nd.op == NodeOp::VARZ) return "v";
+            if (nd.op == NodeOp::CONST) {
+                uint32_t u;
+                memcpy(&u, &nd.cval, 4);
+                char b[16];
+                snprintf(b, sizeof b, "#%08x", u);
+                return b;
+            }
+            std::string r = "(" + std::to_string((int)nd.op) + ":" + std::to_string(nd.ipow);
+            if (nd.a >= 0) r += "," + canon(nd.a);
+            if (nd.b >= 0) r += "," + canon(nd.b);
+            return r + ")";
+        };
+        bool sym = !hoisted[0].empty() && hoisted[0].size() == hoisted[1].size() && hoisted[0].size() == hoisted[2].size();
+        std::vector<int> perm[3];
+        if (sym) {
+            std::vector<std::string> c0;
+            for (int i : hoisted[0]) c0.push_back(canon(i));
+            for (int v = 1; v < 3 && sym; ++v) {
+                std::vector<char> used(c0.size(), 0);
+                for (int i : hoisted[v]) {
+                    const std::string ci = canon(i);
+                    int hit = -1;
+                    for (size_t j = 0; j < c0.size(); ++j)
+                        if (!used[j] && c0[j] == ci) {
+                            hit = (int)j;
+                            break;
+                        }
+                    if (hit < 0) {
+                        sym = false;
+                        break;
+                    }
+                    used[hit] = 1;
+                    perm[v].push_back(hit);
+                }
+            }
+        }
+        if (sym) {
+            s += "#define MC_TAB_SYM 1\n";
+            for (int v = 1; v < 3; ++v) {
+                s += std::string("__device__ __forceinline__ void mc_tab_sym_") + var[v] + "(const float (&C)[MC_TAB_NX], float (&U)[MC_TAB_N" + VAR[v] + "]) {\n";
+                for (size_t k = 0; k < perm[v].size(); ++k) s += "    U[" + std::to_string(k) + "] = C[" + std::to_string(perm[v][k]) + "];\n";
+                s += "}\n";
+            }
+        }
     }
     s += "__device__ __forceinline__ float mc_f_t(float x, float y, float z, const float (&UX)[MC_TAB_NX], const float (&UY)[MC_TAB_NY], "
          "const float (&UZ)[MC_TAB_NZ]) {\n    (void)x; (void)y; (void)z; (void)UX; (void)UY; (void)UZ;\n";

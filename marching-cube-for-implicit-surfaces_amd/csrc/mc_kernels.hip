@@ -1434,6 +1434,110 @@ __device__ __forceinline__ void mc_emit_axis(const McParams& p, const float* __r
         }
     }
 }
+#ifdef MC_TAB_SYM
+// The same for equations whose three axes carry the SAME one-variable functions (MC_TAB_SYM, mc_expr.cpp; the gyroid): the
+// vertices of all three edge directions in ONE pass, one lane per vertex.  The per-axis passes each fill their 64 lanes with
+// a third of the chunk's ~125 vertices -- three steps at 42 lanes; this is two at 63.  What a lane evaluates (the functions
+// at the interpolated coordinate and at +- h) it evaluates with mc_f_ux whatever its axis -- the lists are the same functions,
+// mc_tab_sym_y / _z reorder them -- and what it reads from the tables it reads for all three axes, keeping per axis the one
+// that applies: the same operations on the same operands as mc_emit_axis<AX>, lane by lane.
+__device__ __forceinline__ void mc_emit_sym(const McParams& p, const float* __restrict__ axis, u32 cnt, const unsigned short* item,
+                                            const u32* recw, const u32* segrec, float* vc, float iso, float h, bool want_normals, int lane) {
+    const u32 ts = mc_tab_stride(p.n1);
+    const float* __restrict__ tab = p.tab;
+#ifdef MC_UNIT_SCALE
+    const float sx = 1.0f, sy = 1.0f, sz = 1.0f;
+#else
+    const float sx = p.sx, sy = p.sy, sz = p.sz;
+#endif
+    for (u32 i0 = 0; i0 < cnt; i0 += 64u) {
+        const u32 i = i0 + (u32)lane;
+        if (i < cnt) {
+            const u32 it = item[i];
+            const int e = (int)(it >> 6);
+            const u32 rw = recw[it & 63u];
+            const u32 s2 = segrec[rw & 63u];
+            const int bx = (int)(((s2 >> 22) & 7u) * (u32)MC_SEG + ((rw >> 6) & 0xFFu)) + (int)((MC_EDGE_OX >> e) & 1u);
+            const int by = (int)(s2 & 2047u) + (int)((MC_EDGE_OY >> e) & 1u);
+            const int bz = (int)((s2 >> 11) & 2047u) + (int)((MC_EDGE_OZ >> e) & 1u);
+            const int ax = edge_axis(e);
+            const int dx = ax == 0 ? 1 : 0, dy = ax == 1 ? 1 : 0, dz = ax == 2 ? 1 : 0;
+            const float x0 = axis[bx], y0 = axis[by], z0 = axis[bz];
+            const float x1 = axis[bx + dx], y1 = axis[by + dy], z1 = axis[bz + dz];  // (the upper corner differs on the edge's axis only)
+            const float c0 = ax == 0 ? x0 : ax == 1 ? y0 : z0;
+            const float c1 = ax == 0 ? x1 : ax == 1 ? y1 : z1;
+            float UX[MC_TAB_NX], UY[MC_TAB_NY], UZ[MC_TAB_NZ], UX1[MC_TAB_NX], UY1[MC_TAB_NY], UZ1[MC_TAB_NZ];
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NX; ++k) {
+                UX[k] = mc_tab_ptr(tab, ts, 0, 0, k)[bx];
+                UX1[k] = mc_tab_ptr(tab, ts, 0, 0, k)[bx + dx];
+            }
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NY; ++k) {
+                UY[k] = mc_tab_ptr(tab, ts, 1, 0, k)[by];
+                UY1[k] = mc_tab_ptr(tab, ts, 1, 0, k)[by + dy];
+            }
+#pragma unroll
+            for (int k = 0; k < MC_TAB_NZ; ++k) {
+                UZ[k] = mc_tab_ptr(tab, ts, 2, 0, k)[bz];
+                UZ1[k] = mc_tab_ptr(tab, ts, 2, 0, k)[bz + dz];
+            }
+            const float v0 = mc_f_t(sx * x0, sy * y0, sz * z0, UX, UY, UZ), v1 = mc_f_t(sx * x1, sy * y1, sz * z1, UX1, UY1, UZ1);
+            const float pu = mc_interp(iso, c0, c1, v0, v1);  // marching.cpp:557-583 for an edge walked upwards
+            const float pd = mc_interp(iso, c1, c0, v1, v0);  // ... downwards (edges 2, 3, 6, 7)
+            const float qx = ax == 0 ? pu : x0, qy = ax == 1 ? pu : y0, qz = ax == 2 ? pu : z0;
+            float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            if (want_normals) {
+                // the functions at (q, q + h, q - h) on the edge's axis: evaluated (in x's order, then put into the axis' own)
+                const float sa = ax == 0 ? sx : ax == 1 ? sy : sz;
+                float C0[MC_TAB_NX], Cp[MC_TAB_NX], Cm[MC_TAB_NX];
+                mc_f_ux(sa * pu, C0);
+                mc_f_ux(sa * (pu + h), Cp);
+                mc_f_ux(sa * (pu - h), Cm);
+                float Y0[MC_TAB_NY], Yp[MC_TAB_NY], Ym[MC_TAB_NY], Z0[MC_TAB_NZ], Zp[MC_TAB_NZ], Zm[MC_TAB_NZ];
+                mc_tab_sym_y(C0, Y0);
+                mc_tab_sym_y(Cp, Yp);
+                mc_tab_sym_y(Cm, Ym);
+                mc_tab_sym_z(C0, Z0);
+                mc_tab_sym_z(Cp, Zp);
+                mc_tab_sym_z(Cm, Zm);
+                // per axis: those when it is the edge's axis, the tables (lattice coordinate, + h, - h: kinds 0, 1, 2) when not
+                float UXq[MC_TAB_NX], UXp[MC_TAB_NX], UXm[MC_TAB_NX], UYq[MC_TAB_NY], UYp[MC_TAB_NY], UYm[MC_TAB_NY], UZq[MC_TAB_NZ], UZp[MC_TAB_NZ],
+                    UZm[MC_TAB_NZ];
+#pragma unroll
+                for (int k = 0; k < MC_TAB_NX; ++k) {
+                    const float tp = mc_tab_ptr(tab, ts, 0, 1, k)[bx], tm = mc_tab_ptr(tab, ts, 0, 2, k)[bx];
+                    UXq[k] = ax == 0 ? C0[k] : UX[k];
+                    UXp[k] = ax == 0 ? Cp[k] : tp;
+                    UXm[k] = ax == 0 ? Cm[k] : tm;
+                }
+#pragma unroll
+                for (int k = 0; k < MC_TAB_NY; ++k) {
+                    const float tp = mc_tab_ptr(tab, ts, 1, 1, k)[by], tm = mc_tab_ptr(tab, ts, 1, 2, k)[by];
+                    UYq[k] = ax == 1 ? Y0[k] : UY[k];
+                    UYp[k] = ax == 1 ? Yp[k] : tp;
+                    UYm[k] = ax == 1 ? Ym[k] : tm;
+                }
+#pragma unroll
+                for (int k = 0; k < MC_TAB_NZ; ++k) {
+                    const float tp = mc_tab_ptr(tab, ts, 2, 1, k)[bz], tm = mc_tab_ptr(tab, ts, 2, 2, k)[bz];
+                    UZq[k] = ax == 2 ? Z0[k] : UZ[k];
+                    UZp[k] = ax == 2 ? Zp[k] : tp;
+                    UZm[k] = ax == 2 ? Zm[k] : tm;
+                }
+                const float fx = sx * qx, fy = sy * qy, fz = sz * qz;
+                const float gx = mc_f_t(sx * (qx + h), fy, fz, UXp, UYq, UZq) - mc_f_t(sx * (qx - h), fy, fz, UXm, UYq, UZq);
+                const float gy = mc_f_t(fx, sy * (qy + h), fz, UXq, UYp, UZq) - mc_f_t(fx, sy * (qy - h), fz, UXq, UYm, UZq);
+                const float gz = mc_f_t(fx, fy, sz * (qz + h), UXq, UYq, UZp) - mc_f_t(fx, fy, sz * (qz - h), UXq, UYq, UZm);
+                if (!mc_unit_gradient(gx, gy, gz, nx, ny, nz)) nx = __builtin_nanf("");  // marker: see D
+            }
+            float4* o = (float4*)(vc + 8u * i);
+            o[0] = make_float4(qx, qy, qz, pd);
+            o[1] = make_float4(nx, ny, nz, 0.0f);
+        }
+    }
+}
+#endif
 #endif
 
 // One wave = one GROUP of 64 consecutive segments; its records (= active cells, written by mc_classify) are taken in
@@ -1482,7 +1586,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
     __shared__ u32 s_own[MC_WPB_ES][64];    // ... S | first slot << 12
     __shared__ u32 s_list[MC_WPB_ES][320];  // triangles of the chunk: slot of corner k << 8k | (axis taken from p_down, 3 = none) << 24 + 2k
     __shared__ unsigned short s_item[MC_WPB_ES][MC_VCAP];  // vertices to compute: lane | edge << 6
-#ifdef MC_TAB
+#if defined(MC_TAB) && !defined(MC_TAB_SYM)
     __shared__ unsigned char s_axl[MC_WPB_ES][3 * MC_VCAP];  // ... their indices, sorted by the axis of the edge
 #endif
     // No table in LDS, no workgroup barrier: the waves of a workgroup are independent (a workgroup is only a launch
@@ -1689,7 +1793,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         if (rn < nrec) rec_n = recs[rbase[lo_n] + (rn - actoff[lo_n])];
 
         // ---- C. one lane per computed vertex
-#ifdef MC_TAB
+#if defined(MC_TAB_SYM)
+        mc_emit_sym(p, axis, M, item, recw, segrec, vc, iso, h, want_normals, lane);
+#elif defined(MC_TAB)
         {
             // the chunk's vertices by the axis of their edge, then one pass per axis (mc_emit_axis)
             unsigned char* axl = s_axl[w];
