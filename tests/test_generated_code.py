@@ -78,6 +78,14 @@ int main() {
         mc_f_uz(z, UZ);
         const float a = mc_f(x, y, z), b = mc_f_t(x, y, z, UX, UY, UZ);
         if (std::memcmp(&a, &b, 4) && !(a != a && b != b)) ++bad_tab;
+#ifdef MC_TAB_SYM   // the three axes carry the same functions: x's list, reordered, IS y's and z's (what mc_emit_sym relies on)
+        float CY[MC_TAB_NX], CZ[MC_TAB_NX], SY[MC_TAB_NY], SZ[MC_TAB_NZ];
+        mc_f_ux(y, CY);
+        mc_f_ux(z, CZ);
+        mc_tab_sym_y(CY, SY);
+        mc_tab_sym_z(CZ, SZ);
+        if (std::memcmp(SY, UY, sizeof UY) || std::memcmp(SZ, UZ, sizeof UZ)) ++bad_tab;
+#endif
     }
 #endif
 #ifdef MC_IV_NY
@@ -156,6 +164,17 @@ def test_tabulated_form_is_mc_f(mc, trig, tmp_path, eq):
     src = mc.expr_dump(eq)
     assert "#define MC_TAB 1" in src and "float mc_f_t(" in src
     run_host(mc, tmp_path, eq, 2.0)          # asserts bit equality of mc_f_t o (mc_f_ux, mc_f_uy, mc_f_uz) with mc_f
+
+
+@pytest.mark.parametrize("eq,sym", [(GYROID, True), ("cos(x)*cos(y)*cos(z)-0.1", True), ("sin(2x)*y+sin(2y)*z+sin(2z)*x", True),
+                                    ("sin(x)+sin(y)+cos(z)", False), ("sin(3y)*x+z*z-0.2", False), ("sin(2x)*y+sin(3y)*z+sin(2z)*x", False)])
+def test_same_functions_on_all_axes_are_recognised(mc, trig, tmp_path, eq, sym):
+    """MC_TAB_SYM (mc_emit's one pass over all three edge directions): defined exactly when the axes' tabulated functions are
+    the same up to order; the host run checks that x's list, reordered, gives y's and z's bits."""
+    src = mc.expr_dump(eq)
+    assert ("#define MC_TAB_SYM 1" in src) == sym
+    if "#define MC_TAB 1" in src:
+        run_host(mc, tmp_path, eq, 2.0)
 
 
 @pytest.mark.parametrize("eq", NOT_TABULATED)
