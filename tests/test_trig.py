@@ -104,6 +104,11 @@ def test_eval_points_bit_exact(mc, orc, ext, eq):
     ("sin(x)*sin(y)*sin(z)+sin(x)*cos(y)*cos(z)+cos(x)*sin(y)*cos(z)+cos(x)*cos(y)*sin(z)", 40, 0.0, (6.2831853,) * 3),  # diamond
     ("sin(x)/cos(y)-z", 40, 0.0, (3.0, 3.0, 1.0)),                             # not boundable: sampling walk, inf / NaN cells
     ("x^2+y^2+z^2-sin(4x)^2", 40, 0.5, (1.0, 1.0, 1.0)),
+    # the same functions on all three axes (MC_TAB_SYM: mc_emit's one pass over all edge directions) with a scale per axis,
+    # one function next to plain variables, and a product
+    (GYROID, 72, 0.1, (6.2831853, 9.424778, 12.566371)),
+    ("sin(2x)*y+sin(2y)*z+sin(2z)*x", 56, 0.05, (2.0, 2.5, 3.0)),
+    ("cos(x)*cos(y)*cos(z)-0.1", 64, 0.0, (6.2831853,) * 3),
 ])
 def test_sweep_matches_oracle(mc, orc, ext, eq, n, iso, scale):
     step = float(f32(2.0) / f32(n))
