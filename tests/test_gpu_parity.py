@@ -6,6 +6,8 @@ vectors; normals within 1e-6 of the oracle's N1 definition.
 """
 import os
 
+import zlib
+
 import numpy as np
 import pytest
 
@@ -49,7 +51,12 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
     # for expensive f) must write the same bytes
     # ... and so must 63-row classify tiles (small grids get shorter ones by default)
     # ... and mc_emit with its waves one per group (FLAG_BATCH) or four per group (an expensive f on a small grid)
-    for force in (mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED, mc.FLAG_EMIT_SHARED | mc.FLAG_BATCH, mc.FLAG_TILE63):
+    # (the one-wave-per-group launch is a second module per equation: compiled for BASELINE's equation_3 and for every other
+    # equation besides, by a hash of its text)
+    forces = [mc.FLAG_EMIT_DIRECT, mc.FLAG_EMIT_SHARED, mc.FLAG_TILE63]
+    if eq == EQ["eq3"] or zlib.crc32(eq.encode()) % 2 == 0:
+        forces.insert(2, mc.FLAG_EMIT_SHARED | mc.FLAG_BATCH)
+    for force in forces:
         r2 = ctx.march(eq, step, iso, scale, flags | force, z[0], z[1])
         if force == mc.FLAG_TILE63:
             assert np.array_equal(r2.codes(), o.codes), "cube codes differ with 63-row tiles"
