@@ -231,6 +231,7 @@ __device__ __forceinline__ u32 mc_tab_stride(int n1) { return ((u32)n1 + 1u + 63
 __device__ __forceinline__ const float* mc_tab_ptr(const float* tab, u32 stride, int v, int w, int k) {
     return tab + (u32)((v * 3 + w) * MC_TAB_NK + k) * stride;
 }
+#ifndef MC_ONLY_INDEX_KERNELS  // (the module of the index kernels, compiled when MC_FLAG_INDEXED is first used, leaves the sweep kernels out)
 extern "C" __global__ __launch_bounds__(256) void mc_tabulate(const McParams* __restrict__ P, float* __restrict__ tab) {
     const McParams p = *P;
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
@@ -257,6 +258,7 @@ extern "C" __global__ __launch_bounds__(256) void mc_tabulate(const McParams* __
         for (int k = 0; k < MC_TAB_NZ; ++k) tab[(u32)((2 * 3 + w) * MC_TAB_NK + k) * stride + (u32)i] = UZ[k];
     }
 }
+#endif  // MC_ONLY_INDEX_KERNELS
 #endif
 
 // Wavefront (64-lane) inclusive prefix sum in 7 DPP adds: row_shr 1,2,3 / 4 / 8 inside the
@@ -704,6 +706,7 @@ __device__ __forceinline__ void mc_add_group_sums(u64* __restrict__ grpsum, u32 
     if (last && run) atomicAdd(&grpsum[key], (u64)(run & 0x1FFFFu) | ((u64)(run >> 17) << 32));
 }
 
+#ifndef MC_ONLY_INDEX_KERNELS  // (the module of the index kernels, compiled when MC_FLAG_INDEXED is first used, leaves the sweep kernels out)
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc_classify(const McParams* __restrict__ P, u8* __restrict__ codes,
                                                                          uint2* __restrict__ segcb, u32* __restrict__ recs,
                                                                          u64* __restrict__ grpsum) {
@@ -1275,6 +1278,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
     // group sums for the scan (group = 64 consecutive segments): triangles | active cells << 32
     mc_add_group_sums(grpsum, c, sg, lane);
 }
+#endif  // MC_ONLY_INDEX_KERNELS
 
 // =============================================================== K3: emit
 // ---- geometry of the 12 cell edges (marching_lookup.h:10-23 over the corner layout of marching.cpp:471-472)
@@ -1573,6 +1577,7 @@ struct McEmitK {
     float step, sx, sy, sz;
     const float* tab;     // MC_TAB: McParams::tab
 };
+#ifndef MC_ONLY_INDEX_KERNELS  // (the module of the index kernels, compiled when MC_FLAG_INDEXED is first used, leaves the sweep kernels out)
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                      float* __restrict__ verts, const McEmitK k) {
@@ -1910,6 +1915,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_ES) void mc_emit(const McPar
         rec = rec_n;
     }
 }
+#endif  // MC_ONLY_INDEX_KERNELS
 
 struct McVert {
     float x, y, z;
@@ -1953,6 +1959,7 @@ __device__ __forceinline__ McVert mc_vertex(const McParams& p, const float* s_ax
 // the list index is the triangle's position in the reference's emission order.  Phase 2, one lane per output VERTEX: edge
 // lookup (nibble-packed table row in LDS), two corner evaluations, the interpolation, the central-difference gradient of f
 // for the normal, 24-byte store.
+#ifndef MC_ONLY_INDEX_KERNELS  // (the module of the index kernels, compiled when MC_FLAG_INDEXED is first used, leaves the sweep kernels out)
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                      const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                      float* __restrict__ verts) {
@@ -2178,7 +2185,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
         have = have_next;
     }
 }
+#endif  // MC_ONLY_INDEX_KERNELS
 
+#ifndef MC_NO_INDEX_KERNELS
 // =============================================================== indexed mesh (MC_FLAG_INDEXED)
 // Poly_Data as the reference builds it (marching.cpp:599-654): vertex_list / tri_list with the vertices welded.  The
 // reference welds through a std::set whose comparator calls two points equal when they are closer than 1e-6 on every
@@ -2861,9 +2870,12 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
     MC_GROUP_LDS_SHARED_END
 }
 
+#endif  // MC_NO_INDEX_KERNELS
 // =============================================================== evaluate points
 // Evaluator::evaluate(x,y,z) (evaluator.cpp:53) for a batch of points: out[i] = f(xyz[3i..3i+2]).
+#ifndef MC_ONLY_INDEX_KERNELS  // (the module of the index kernels, compiled when MC_FLAG_INDEXED is first used, leaves the sweep kernels out)
 extern "C" __global__ __launch_bounds__(256) void mc_eval(const float* __restrict__ xyz, float* __restrict__ out, u64 n) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
     if (i < n) out[i] = mc_f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
 }
+#endif  // MC_ONLY_INDEX_KERNELS
