@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 3
+#define MC_ABI_VERSION 4
 
 /* Status codes (the reference returns bool / throws std::exception without text:
  * evaluator.cpp:10-13, marching.cpp:226-238). */
@@ -71,12 +71,17 @@ enum {
     MC_FLAG_SEAM = 1024u,      /* with MC_FLAG_INDEXED on a Z slab: weld the slab as a PART OF THE WHOLE     */
                                /* GRID, so that the slabs' vertex_list / tri_list, concatenated in slab order, */
                                /* are the single sweep's Poly_Data bit for bit (see mc_index_rebase)          */
-    MC_FLAG_BATCH = 4096u      /* the caller keeps SEVERAL sweeps in flight (one context each): choose for     */
+    MC_FLAG_BATCH = 4096u,     /* the caller keeps SEVERAL sweeps in flight (one context each): choose for     */
                                /* throughput where that differs from the fastest single sweep -- on small grids */
                                /* the emit kernel of an expensive f otherwise puts 4 waves on each group of     */
                                /* cells, which shortens one sweep by 8-20 % and costs a batch 9 %.  The output  */
                                /* does not change                                                              */
+    MC_FLAG_ORDER_Z = 8192u,   /* diagnostic: classify launches the slab's layers in z order ...                */
+    MC_FLAG_ORDER_MIDDLE_OUT = 16384u /* ... or from the slab's middle outwards (by default the library times  */
+                               /* both orders on an equation's first sweeps and keeps the faster); the output  */
+                               /* must not change                                                              */
 };
+#define MC_FLAG_LAYER_ORDER_MASK (MC_FLAG_ORDER_Z | MC_FLAG_ORDER_MIDDLE_OUT)
 
 typedef struct mc_context mc_context; /* one per GPU: stream, buffers, compiled-equation cache */
 
@@ -206,8 +211,11 @@ int mc_copy_indexed(mc_context *ctx, float *vertex_list, uint32_t *tri_list, flo
  * (the j-th vertex from the END of that slab's list is -j) -- and
  *     mc_index_rebase(ctx, offset)     offset = number of vertices owned by all slabs below (the one figure the ranks
  *                                      exchange: an all-gather of n_verts, like the triangle counts)
- * adds `offset` to every entry (mod 2^32), after which tri_list indexes the concatenation of the slabs' vertex lists.
- * Call it once per sweep, before mc_copy_indexed.  The whole grid in one slab: MC_FLAG_SEAM changes nothing. */
+ * makes every entry index the concatenation of the slabs' vertex lists.  The offset is a STATE of the sweep's tri_list,
+ * not an increment: calling it again with the same offset changes nothing (a retry after a failed exchange is safe), with
+ * another offset the list is re-targeted; a new sweep starts from offset 0.  Before the call (offset 0) an entry that
+ * refers to a vertex of the slab below reads as a wrapped negative number -- mc_copy_indexed hands it out as it is.
+ * The whole grid in one slab: MC_FLAG_SEAM changes nothing. */
 int mc_index_rebase(mc_context *ctx, uint64_t vertex_offset);
 
 /* Constraints: Marching::set_constraint0..2(lhs, op, rhs) (Source/marching.h:105-108, marching.cpp:173-200) and
@@ -256,6 +264,68 @@ int mc_graph_replay_async(mc_context *ctx, float iso);
 int mc_graph_wait(mc_context *ctx, mc_result *res);
 /* The HIP stream (hipStream_t) every kernel of this context runs on, for callers that order their own work after a sweep. */
 void *mc_stream(mc_context *ctx);
+
+/* -- multi-device sweep: Marching::recalculate() (marching.cpp:368-384) with the cell layers cut into one contiguous Z slab
+ *    per device (SURVEY 8b "device list", 8e).  The sweep is z-major (marching.cpp:375), so the slabs' triangle lists
+ *    concatenated in slab order ARE the single sweep's list; f is analytic, every device evaluates its own top sample plane
+ *    and no halo exists.  The only figures that cross devices are the per-slab counts, from which each slab gets its offset.
+ *    Two forms: ONE process driving several devices (mc_march_sharded: a context per device, host threads, the counts are
+ *    plain host reads), and one process PER device (mc_comm_* + mc_march_rank: the counts travel by an RCCL all-gather over
+ *    xGMI; librccl.so is loaded on first use, a process that never calls mc_comm_* does not need it). */
+
+/* Layers [*z_begin, *z_end) of slab `part` when layers [0, n_layers) are cut into `parts` near-equal contiguous slabs
+ * (the first n_layers % parts slabs get one layer more). */
+void mc_shard_layers(int n_layers, int parts, int part, int *z_begin, int *z_end);
+
+typedef struct mc_shard {
+    int32_t z_begin, z_end;  /* cell layers this slab swept                                                           */
+    uint64_t tri_offset;     /* triangles of all slabs below it = index of its first triangle in the whole grid's list */
+    uint64_t vert_offset;    /* MC_FLAG_INDEXED: vertices owned by all slabs below it; ALREADY added to its tri_list   */
+                             /* (mc_index_rebase), which therefore indexes the concatenated vertex_list                */
+    uint64_t n_tris_total;   /* the whole grid's counts (the same in every entry)                                      */
+    uint64_t n_verts_total;
+} mc_shard;
+
+/* One process, n contexts (one per device of the caller's device list; a device may appear more than once -- its contexts'
+ * sweeps then overlap on it).  p describes the WHOLE sweep (its z_begin / z_end give the range that is cut, normally 0, -1);
+ * bounds: NULL = near-equal slabs (mc_shard_layers), else n + 1 ascending layer indices (a caller that balances slabs by
+ * measured cost passes its own).  Slab i runs on ctxs[i] -- all slabs at once, one host thread each -- and leaves results[i]
+ * exactly as mc_march would; shards[i] (optional) receives its offsets.  With MC_FLAG_INDEXED every slab is welded as a part
+ * of the whole grid (MC_FLAG_SEAM is implied) and re-based, so the slabs' vertex_list / tri_list / normals concatenated in
+ * slab order are the single sweep's Poly_Data bit for bit.  Constraints are per context: set them on every context
+ * (mc_set_constraint).  Seed mode (whole grid only) is refused.  On an error the first failing slab's code and text are
+ * reported. */
+int mc_march_sharded(mc_context *const *ctxs, int n, const mc_params *p, const int32_t *bounds, mc_result *results,
+                     mc_shard *shards);
+/* The slabs' results of the last mc_march_sharded on these contexts, concatenated in slab order into host memory: what
+ * mc_copy_vertices / mc_copy_indexed / mc_copy_codes give for a single sweep.  Any output pointer may be NULL. */
+int mc_copy_sharded_vertices(mc_context *const *ctxs, int n, float *host, uint64_t max_tris);
+int mc_copy_sharded_indexed(mc_context *const *ctxs, int n, float *vertex_list, uint32_t *tri_list, float *normals,
+                            uint64_t max_verts, uint64_t max_tris);
+int mc_copy_sharded_codes(mc_context *const *ctxs, int n, uint8_t *host, uint64_t max_bytes);
+
+/* One process per device.  A communicator spans `world` processes; rank 0 makes an id (mc_comm_get_id: ncclGetUniqueId),
+ * the application hands its 128 bytes to the other ranks by whatever channel it has (MPI, a file, torch.distributed's
+ * store), and every rank calls mc_comm_create with its context (ncclCommInitRank on the context's device).
+ * MC_ERR_HIP when librccl.so cannot be loaded or RCCL reports an error. */
+#define MC_COMM_ID_BYTES 128
+typedef struct mc_comm mc_comm;
+int mc_comm_get_id(uint8_t id[MC_COMM_ID_BYTES]);
+int mc_comm_create(mc_context *ctx, const uint8_t id[MC_COMM_ID_BYTES], int world, int rank, mc_comm **out);
+void mc_comm_destroy(mc_comm *comm);
+/* This rank's slab of the sweep p describes (layers cut by mc_shard_layers(., world, rank), or by `bounds` -- world + 1
+ * ascending layer indices, the same on every rank), then ONE ncclAllGather of {n_tris, n_verts} (16 bytes per rank) on a
+ * side stream ordered behind the sweep, from which `shard` gets this rank's offsets and the totals; with MC_FLAG_INDEXED
+ * the slab is welded with MC_FLAG_SEAM and its tri_list re-based.  Collective: every rank of the communicator calls it. */
+int mc_march_rank(mc_comm *comm, const mc_params *p, const int32_t *bounds, mc_result *res, mc_shard *shard);
+/* The steady-state form of the same exchange, without the host in the loop (a caller that replays a captured sweep,
+ * mc_graph_replay_async, once per frame): mc_comm_gather_async enqueues -- behind everything already enqueued on the
+ * context's stream -- a copy of the sweep's device-side {n_tris, n_active} words (mc_result.d_totals) and their all-gather
+ * on the communicator's side stream, and orders the context's NEXT sweep behind the copy (its scan clears those words);
+ * mc_comm_wait blocks until every gather enqueued so far is done and hands out the LAST one: counts[2 * r] = n_tris and
+ * counts[2 * r + 1] = n_active of rank r (2 * world entries).  d_totals: the sweep's mc_result.d_totals. */
+int mc_comm_gather_async(mc_comm *comm, const uint64_t *d_totals);
+int mc_comm_wait(mc_comm *comm, uint64_t *counts);
 
 #ifdef __cplusplus
 }

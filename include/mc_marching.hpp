@@ -34,7 +34,9 @@
 // recalculate() return false and last_error() non-empty instead of crashing.
 //
 // Evaluator() / Marching() work like the reference's (evaluator.h:61, marching.h:75: no arguments): they share one
-// process-wide GPU context on device 0, created on first use.  The Context& overloads put an object on another GPU.
+// process-wide GPU context on device 0, created on first use.  The Context& overloads put an object on another GPU,
+// and Marching::set_devices({0, 1, ...}) spreads ONE recalculate() over several: the cell layers are cut into one Z slab
+// per listed device, swept at once (mc_march_sharded), and get_poly_data() holds the same Poly_Data as a single sweep.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -42,6 +44,7 @@
 #include <exception>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -325,17 +328,44 @@ private:
 
     // This object's constraints, seed mode and seed -> the (possibly shared) GPU context.  The library ignores calls
     // that change nothing, so this is cheap when one object sweeps repeatedly.
-    bool push_state() {
+    bool push_state(mc_context* c) {
         for (int i = 0; i < 3; ++i) {
             const Constraint& cn = cons_[i];
-            if (cn.valid && mc_set_constraint(ctx_.get(), i, cn.lhs.c_str(), cn.ops.c_str(), cn.rhs) != MC_OK) return false;
-            if (mc_use_constraint(ctx_.get(), i, (cn.valid && cn.in_use) ? 1 : 0) != MC_OK) return false;  // marching.cpp:258
+            if (cn.valid && mc_set_constraint(c, i, cn.lhs.c_str(), cn.ops.c_str(), cn.rhs) != MC_OK) return false;
+            if (mc_use_constraint(c, i, (cn.valid && cn.in_use) ? 1 : 0) != MC_OK) return false;  // marching.cpp:258
         }
-        if (mc_set_seed(ctx_.get(), seed_[0], seed_[1], seed_[2]) != MC_OK) return false;
-        return mc_seed_mode(ctx_.get(), seed_mode_ ? 1 : 0) == MC_OK;
+        if (mc_set_seed(c, seed_[0], seed_[1], seed_[2]) != MC_OK) return false;
+        return mc_seed_mode(c, seed_mode_ ? 1 : 0) == MC_OK;
+    }
+    bool push_state() {
+        if (!push_state(ctx_.get())) return false;
+        for (auto& c : shard_ctx_)
+            if (!push_state(c->get())) return false;
+        return true;
     }
 
 public:
+    // The device list of this object's sweeps: recalculate() cuts the grid's cell layers into one contiguous
+    // Z slab per entry and sweeps them at once, one context per entry (a device may be listed more than once).  The mesh
+    // get_poly_data() returns is the single sweep's -- the sweep is z-major (marching.cpp:375), so the slabs' lists
+    // concatenate to it, and the indexed mesh is welded across the seams (mc_hip.h: mc_march_sharded).  An empty list
+    // returns to the one context the object was constructed on.  Seed mode needs the whole grid on one device and makes
+    // recalculate() fail while a list of two or more devices is set.  false: a device of the list cannot be used.
+    bool set_devices(const std::vector<int>& devices) {
+        std::vector<std::unique_ptr<Context>> made;
+        try {
+            for (int d : devices) made.emplace_back(new Context(d));
+        } catch (const std::exception& e) {
+            error_ = e.what();
+            return false;
+        }
+        shard_ctx_ = std::move(made);
+        return true;
+    }
+    size_t device_count() const { return shard_ctx_.empty() ? 1 : shard_ctx_.size(); }
+    // the slabs of the last multi-device recalculate(): layers and offsets per device of the list
+    const std::vector<mc_shard>& shards() const { return shards_; }
+
     // true (default): the reference's welded Poly_Data (marching.cpp:599-654), built on the GPU; false: triangle soup
     void set_indexed(bool b) { indexed_ = b; }
 
@@ -369,6 +399,7 @@ public:
         p.flags = indexed ? (MC_FLAG_INDEXED | MC_FLAG_NO_EMIT) : (normals_ ? MC_FLAG_NORMALS : 0u);
         p.z_begin = 0;
         p.z_end = -1;
+        if (!shard_ctx_.empty()) return recalculate_sharded(p, indexed);
         mc_result r{};
         if (mc_march(ctx_.get(), &p, &r) != MC_OK) {
             error_ = mc_last_error();
@@ -406,6 +437,69 @@ public:
         return true;
     }
 
+private:
+    // recalculate() over the device list: one slab per context, all at once; the hand-over is the single sweep's
+    bool recalculate_sharded(const mc_params& p, bool indexed) {
+        const int n = (int)shard_ctx_.size();
+        std::vector<mc_context*> cs;
+        for (auto& c : shard_ctx_) cs.push_back(c->get());
+        std::vector<mc_result> rs((size_t)n);
+        shards_.assign((size_t)n, mc_shard{});
+        if (mc_march_sharded(cs.data(), n, &p, nullptr, rs.data(), shards_.data()) != MC_OK) {
+            error_ = mc_last_error();
+            return false;
+        }
+        last_ = rs[0];
+        uint64_t nt = 0, nv = 0, nc = 0, na = 0;
+        for (const mc_result& r : rs) {
+            nt += r.n_tris;
+            nv += r.n_verts;
+            nc += r.n_cells;
+            na += r.n_active;
+        }
+        last_.z_end = rs[(size_t)n - 1].z_end;
+        last_.n_tris = nt;
+        last_.n_verts = nv;
+        last_.n_cells = nc;
+        last_.n_active = na;
+        last_.d_vertices = nullptr;  // (the device buffers are per slab: results of one context only describe its slab)
+        last_.d_codes = nullptr;
+        last_.d_codes_tail = nullptr;
+        last_.d_vertex_list = nullptr;
+        last_.d_tri_list = nullptr;
+        last_.d_vertex_normals = nullptr;
+        last_.d_totals = nullptr;
+        if (indexed) {
+            poly_data_.vertex_list.resize((size_t)nv * 3);
+            poly_data_.tri_list.resize((size_t)nt * 3);
+            if (normals_) poly_data_.normal_list.resize((size_t)nv * 3);
+            if (mc_copy_sharded_indexed(cs.data(), n, poly_data_.vertex_list.data(), reinterpret_cast<uint32_t*>(poly_data_.tri_list.data()),
+                                        normals_ ? poly_data_.normal_list.data() : nullptr, nv, nt) != MC_OK) {
+                error_ = mc_last_error();
+                return false;
+            }
+            return true;
+        }
+        const size_t nvert = (size_t)nt * 3;
+        std::vector<float> inter(nvert * 6);
+        if (nvert && mc_copy_sharded_vertices(cs.data(), n, inter.data(), nt) != MC_OK) {
+            error_ = mc_last_error();
+            return false;
+        }
+        poly_data_.vertex_list.resize(nvert * 3);
+        poly_data_.normal_list.resize(nvert * 3);
+        poly_data_.tri_list.resize(nvert);
+        for (size_t i = 0; i < nvert; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                poly_data_.vertex_list[3 * i + k] = inter[6 * i + k];
+                poly_data_.normal_list[3 * i + k] = inter[6 * i + 3 + k];
+            }
+            poly_data_.tri_list[i] = (unsigned int)i;
+        }
+        return true;
+    }
+
+public:
     const Poly_Data* get_poly_data() const { return &poly_data_; }  // marching.cpp:656-658
 
     // marching.cpp:771-854 save_poly_to_file: the same ASCII PLY, byte for byte ("element face N "
@@ -497,6 +591,8 @@ private:
     } cons_[3];
 
     Context& ctx_;
+    std::vector<std::unique_ptr<Context>> shard_ctx_;  // set_devices: one context per listed device (empty: ctx_ alone)
+    std::vector<mc_shard> shards_;
     bool indexed_ = true;
     bool seed_mode_ = false;
     Evaluator* evaluator_ = nullptr;   // borrowed, never owned (marching.cpp:140-147)

@@ -23,6 +23,8 @@ MC_OK, MC_ERR_PARSE, MC_ERR_EVAL, MC_ERR_STEP, MC_ERR_ARG, MC_ERR_HIP, MC_ERR_NO
 FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_INDEXED, FLAG_NO_CULL, FLAG_NO_TIMING = 1, 2, 4, 8, 32, 64, 128
 FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED, FLAG_SEAM, FLAG_TILE63 = 256, 512, 1024, 2048
 FLAG_BATCH = 4096   # several sweeps in flight (one context each): choose for throughput where that differs from the fastest single sweep
+FLAG_ORDER_Z, FLAG_ORDER_MIDDLE_OUT = 8192, 16384   # diagnostic: force classify's launch order of the layers
+COMM_ID_BYTES = 128
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -31,6 +33,8 @@ ABI_SYMBOLS = [
     "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
     "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
     "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions", "mc_index_rebase",
+    "mc_shard_layers", "mc_march_sharded", "mc_copy_sharded_vertices", "mc_copy_sharded_indexed", "mc_copy_sharded_codes",
+    "mc_comm_get_id", "mc_comm_create", "mc_comm_destroy", "mc_march_rank", "mc_comm_gather_async", "mc_comm_wait",
 ]
 
 
@@ -47,6 +51,11 @@ class McResult(C.Structure):
                 ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p),
                 ("n_verts", C.c_uint64), ("d_vertex_list", C.c_void_p), ("d_tri_list", C.c_void_p), ("d_vertex_normals", C.c_void_p),
                 ("ms_index", C.c_float), ("d_totals", C.c_void_p), ("emit_shared", C.c_int32)]
+
+
+class McShard(C.Structure):
+    _fields_ = [("z_begin", C.c_int32), ("z_end", C.c_int32), ("tri_offset", C.c_uint64), ("vert_offset", C.c_uint64),
+                ("n_tris_total", C.c_uint64), ("n_verts_total", C.c_uint64)]
 
 
 class McError(RuntimeError):
@@ -104,6 +113,19 @@ def lib():
         L.mc_graph_replay.argtypes = [C.c_void_p, C.c_float, C.POINTER(McResult)]
         L.mc_context_set_extensions.argtypes = [C.c_void_p, C.c_int]
         L.mc_index_rebase.argtypes = [C.c_void_p, C.c_uint64]
+        L.mc_shard_layers.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mc_shard_layers.restype = None
+        L.mc_march_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(McParams), C.POINTER(C.c_int32), C.POINTER(McResult), C.POINTER(McShard)]
+        L.mc_copy_sharded_vertices.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64]
+        L.mc_copy_sharded_indexed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.mc_copy_sharded_codes.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64]
+        L.mc_comm_get_id.argtypes = [C.c_void_p]
+        L.mc_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mc_comm_destroy.argtypes = [C.c_void_p]
+        L.mc_comm_destroy.restype = None
+        L.mc_march_rank.argtypes = [C.c_void_p, C.POINTER(McParams), C.POINTER(C.c_int32), C.POINTER(McResult), C.POINTER(McShard)]
+        L.mc_comm_gather_async.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_comm_wait.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -301,6 +323,111 @@ class Context:
     def stream(self) -> int:
         """The context's hipStream_t as an integer (torch.cuda.ExternalStream(ctx.stream()))."""
         return int(lib().mc_stream(self._h) or 0)
+
+
+def _bounds_arg(bounds, n):
+    if bounds is None:
+        return None
+    if len(bounds) != n + 1:
+        raise ValueError(f"bounds must hold {n + 1} layer indices")
+    return (C.c_int32 * (n + 1))(*[int(b) for b in bounds])
+
+
+class ShardedResult:
+    """Host view of one multi-device sweep (mc_march_sharded): the slabs' Results in slab order, their offsets, and the
+    concatenated arrays -- what a single sweep's Result gives."""
+
+    def __init__(self, sharded, results, shards):
+        self._s = sharded
+        self.slabs = results
+        self.shards = shards
+        self.n_tris = sum(r.n_tris for r in results)
+        self.n_verts = sum(r.n_verts for r in results)
+        self.n_cells = sum(r.n_cells for r in results)
+        self.n_active = sum(r.n_active for r in results)
+
+    def vertices(self) -> np.ndarray:
+        a = np.empty((self.n_tris, 3, 6), dtype=np.float32)
+        if self.n_tris:
+            _check(lib().mc_copy_sharded_vertices(self._s._arr, len(self.slabs), a.ctypes.data, self.n_tris))
+        return a
+
+    def indexed(self):
+        v = np.empty((self.n_verts, 3), dtype=np.float32)
+        n = np.empty((self.n_verts, 3), dtype=np.float32)
+        t = np.empty((self.n_tris, 3), dtype=np.uint32)
+        _check(lib().mc_copy_sharded_indexed(self._s._arr, len(self.slabs), v.ctypes.data, t.ctypes.data, n.ctypes.data, self.n_verts, self.n_tris))
+        return v, t, n
+
+    def codes(self) -> np.ndarray:
+        a = np.empty(self.n_cells, dtype=np.uint8)
+        if self.n_cells:
+            _check(lib().mc_copy_sharded_codes(self._s._arr, len(self.slabs), a.ctypes.data, self.n_cells))
+        return a
+
+
+class Sharded:
+    """One process, a device list: one context per entry (a device may appear several times), the sweep's cell layers cut
+    into one Z slab per context and swept at once (mc_march_sharded; SURVEY 8b "device list")."""
+
+    def __init__(self, devices):
+        self.ctxs = [Context(int(d)) for d in devices]
+        self._arr = (C.c_void_p * len(self.ctxs))(*[c._h for c in self.ctxs])
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+    def march(self, equation, step, iso=0.0, scale=(1.0, 1.0, 1.0), flags=FLAG_NORMALS | FLAG_KEEP_CODES, z_begin=0, z_end=-1,
+              bounds=None) -> ShardedResult:
+        n = len(self.ctxs)
+        p = self.ctxs[0]._params(equation, step, iso, scale, flags, z_begin, z_end)
+        res = (McResult * n)()
+        sh = (McShard * n)()
+        _check(lib().mc_march_sharded(self._arr, n, C.byref(p), _bounds_arg(bounds, n), res, sh))
+        return ShardedResult(self, [Result(c, r) for c, r in zip(self.ctxs, res)], list(sh))
+
+
+class Comm:
+    """One process per device: an RCCL communicator over `world` processes for the sweep's one exchange, the per-rank
+    counts (mc_comm_*).  Rank 0 calls Comm.new_id() and hands the 128 bytes to the others (any channel)."""
+
+    @staticmethod
+    def new_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().mc_comm_get_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", comm_id: bytes, world: int, rank: int):
+        assert len(comm_id) == COMM_ID_BYTES
+        self.ctx, self.world, self.rank = ctx, world, rank
+        h = C.c_void_p()
+        idb = (C.c_uint8 * COMM_ID_BYTES)(*comm_id)
+        _check(lib().mc_comm_create(ctx._h, idb, world, rank, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().mc_comm_destroy(self._h)
+            self._h = None
+
+    def march(self, equation, step, iso=0.0, scale=(1.0, 1.0, 1.0), flags=FLAG_NORMALS | FLAG_KEEP_CODES, z_begin=0, z_end=-1, bounds=None):
+        """This rank's slab + the all-gather of the counts (collective) -> (Result, McShard)."""
+        p = self.ctx._params(equation, step, iso, scale, flags, z_begin, z_end)
+        r, sh = McResult(), McShard()
+        _check(lib().mc_march_rank(self._h, C.byref(p), _bounds_arg(bounds, self.world), C.byref(r), C.byref(sh)))
+        return Result(self.ctx, r), sh
+
+    def gather_async(self, d_totals: int):
+        """Enqueue the all-gather of a sweep's device-side counts (Result.d_totals) behind the context's stream."""
+        _check(lib().mc_comm_gather_async(self._h, C.c_void_p(d_totals)))
+
+    def wait(self) -> np.ndarray:
+        """Block until every gather enqueued is done; (world, 2) uint64 {n_tris, n_active} per rank of the last one."""
+        out = np.zeros((self.world, 2), dtype=np.uint64)
+        _check(lib().mc_comm_wait(self._h, out.ctypes.data))
+        return out
 
 
 # ---- Z-slab sharding across GPUs (one process per GPU; host logic only) -----------------

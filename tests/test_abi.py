@@ -23,7 +23,7 @@ def test_header_symbols_exported(mc):
 
 
 def test_abi_version(mc):
-    assert mc.lib().mc_abi_version() == 3   # v3: MC_FLAG_SEAM + mc_index_rebase (one Poly_Data across Z slabs), per-context extensions
+    assert mc.lib().mc_abi_version() == 4   # v4: the multi-device sweep (mc_march_sharded, mc_comm_*, mc_march_rank), mc_index_rebase as a state
 
 
 def test_no_cpu_fallback(mc):

@@ -555,24 +555,31 @@ def _match_triangle_sets(a, b, tol):
     assert len(np.unique(idx)) == len(b), "not a one-to-one match"
 
 
-@pytest.mark.parametrize("eq,n,seed,scale", [
-    (EQ["sphere"], 32, (1.0, 0.0, 0.0), (1.0, 1.0, 1.0)),        # the whole sphere except the cells the bound check excludes
-    (EQ["sphere"], 32, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),        # a seed cell without a crossing: nothing
-    ("x^2-0.25", 32, (0.5, 0.0, 0.0), (1.0, 1.0, 1.0)),          # two sheets: only the one the seed touches
-    ("x^2-0.25", 32, (-0.52, 0.3, 0.2), (1.0, 1.0, 1.0)),
-    ("x^2-0.25", 32, (-0.5, 0.3, 0.2), (1.0, 1.0, 1.0)),         # the crossing is in the cell next door: nothing
-    (EQ["eq3"], 48, (0.0, 0.33, 0.0), (1.0, 1.0, 1.0)),
-    (EQ["eq8"], 40, (0.0, 0.0, 0.6), (1.0, 1.0, 1.0)),
-    (EQ["sphere"], 40, (0.5, 0.0, 0.0), (2.0, 1.0, 1.5)),        # seed / scale picks the cell (marching.cpp:106-108)
+@pytest.mark.parametrize("eq,n,seed,scale,empty", [
+    (EQ["sphere"], 32, (1.0, 0.0, 0.0), (1.0, 1.0, 1.0), False),  # the whole sphere except the cells the bound check excludes
+    (EQ["sphere"], 32, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), True),   # a seed cell without a crossing: nothing (meant to be empty)
+    ("x^2-0.25", 32, (0.5, 0.0, 0.0), (1.0, 1.0, 1.0), False),    # two sheets: only the one the seed touches
+    ("x^2-0.25", 32, (-0.52, 0.3, 0.2), (1.0, 1.0, 1.0), False),
+    ("x^2-0.25", 32, (-0.5, 0.3, 0.2), (1.0, 1.0, 1.0), True),    # the crossing is in the cell next door: nothing (meant to be empty)
+    # seeds that sit ON the surface (centroids of triangles of the dense sweep): round 3's seeds for these equations lay in
+    # cells without a crossing and compared 0 triangles with 0
+    (EQ["eq3"], 48, (-0.585, -0.126, -0.542), (1.0, 1.0, 1.0), False),   # 5 028 of the dense sweep's 5 316 triangles
+    (EQ["eq8"], 40, (0.008, 0.102, 0.65), (1.0, 1.0, 1.0), False),       # two components: 6 296 ...
+    (EQ["eq8"], 40, (0.181, -0.363, -0.183), (1.0, 1.0, 1.0), False),    # ... and 2 888 of 9 184
+    # seed / scale picks the cell (marching.cpp:106-108): on the stretched sphere's x pole, then on its z side
+    (EQ["sphere"], 40, (1.0, 0.0, 0.0), (2.0, 1.0, 1.5), False),
+    (EQ["sphere"], 40, (0.0, 0.0, 1.0), (2.0, 1.0, 1.5), False),
+    (EQ["sphere"], 40, (0.5, 0.0, 0.0), (2.0, 1.0, 1.5), True),          # inside the stretched sphere: nothing (meant to be empty)
     # whole layers / rows of surface cells: a 64-segment group holds thousands of records (several LDS windows of the
     # component labelling), and the sheets are separate components
-    ("z^2-0.25", 64, (0.1, -0.2, 0.5), (1.0, 1.0, 1.0)),
-    ("y^2-0.25", 64, (0.1, -0.5, 0.3), (1.0, 1.0, 1.0)),
-    ("z^2-0.25", 150, (0.1, -0.2, -0.5), (1.0, 1.0, 1.0)),
-    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.3, 0.2, 0.0), (1.0, 1.0, 1.0)),   # a small sphere inside a large one
-    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.0, 0.0, 0.7746), (1.0, 1.0, 1.0)),
+    ("z^2-0.25", 64, (0.1, -0.2, 0.5), (1.0, 1.0, 1.0), False),
+    ("y^2-0.25", 64, (0.1, -0.51, 0.3), (1.0, 1.0, 1.0), False),
+    ("y^2-0.25", 64, (0.1, 0.5, 0.3), (1.0, 1.0, 1.0), False),
+    ("z^2-0.25", 150, (0.1, -0.2, -0.5), (1.0, 1.0, 1.0), False),
+    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.3, 0.2, 0.0), (1.0, 1.0, 1.0), False),   # a small sphere inside a large one
+    ("(x^2+y^2+z^2-0.6)*((x-0.3)^2+y^2+z^2-0.04)", 48, (0.0, 0.0, 0.7746), (1.0, 1.0, 1.0), False),
 ])
-def test_seed_mode(mc, orc, eq, n, seed, scale):
+def test_seed_mode(mc, orc, eq, n, seed, scale, empty):
     step = step_of(n)
     c = mc.Context(0)
     try:
@@ -581,6 +588,7 @@ def test_seed_mode(mc, orc, eq, n, seed, scale):
         r = c.march(eq, step, 0.0, scale)
         o = orc.march_seed(eq, step, seed, 0.0, scale, pow_mode=orc.POW_EXACT)
         assert r.n_tris == o.n_tris
+        assert (r.n_tris == 0) == empty        # a case that compares nothing with nothing must say so
         # same triangles, the reference's in breadth-first order and at cell positions -1 + k*step (ulps off the lattice)
         _match_triangle_sets(r.vertices()[:, :, :3], o.soup, TOL_POS)
         # the code volume is the dense sweep's: seed mode only selects triangles
@@ -759,10 +767,11 @@ def test_random_constraints_match_the_oracle(mc, orc, seed):
         c.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_LARGE", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MC_RANDOM_LARGE", "24"))))
 def test_random_equations_on_multi_chunk_grids(mc, orc, seed):
     """Random equations on grids around the 256-cell chunk boundary (ragged last chunk, tail plane for 1..4 cells,
-    several chunks) and random Z slabs: bit for bit against the oracle."""
+    several chunks) and random Z slabs: bit for bit against the oracle -- and the interval walk (row, block and lane level)
+    against the sampling walk (MC_FLAG_NO_CULL) on the same slab, byte for byte."""
     rng = np.random.default_rng(9000 + seed)
     eq = _random_expr(rng) + "-" + f"{rng.uniform(0.05, 1.0):.3g}"
     if mc.expr_validate(eq) != 0:
@@ -779,6 +788,56 @@ def test_random_equations_on_multi_chunk_grids(mc, orc, seed):
         o = orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=3, z_begin=zb, z_end=ze)
         assert np.array_equal(r.codes(), o.codes), (eq, n, zb, ze)
         assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active), (eq, n, zb, ze)
-        assert_same_floats(r.vertices()[:, :, :3], o.soup, str((eq, n, zb, ze)))
+        rv = r.vertices()
+        assert_same_floats(rv[:, :, :3], o.soup, str((eq, n, zb, ze)))
+        nc = c.march(eq, step, iso, flags=mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | mc.FLAG_NO_CULL, z_begin=zb, z_end=ze)
+        assert np.array_equal(nc.codes(), o.codes), ("NO_CULL", eq, n, zb, ze)
+        assert_same_floats(nc.vertices(), rv, "NO_CULL " + str((eq, n, zb, ze)))
+    finally:
+        c.close()
+
+
+def test_layer_launch_order_does_not_change_the_output(mc, ctx):
+    """mc_classify launches a slab's layers in z order or from the middle outwards, whichever it measured faster on the
+    equation's first sweeps (equation_3 at 513^3 is where middle-out wins).  Forced either way (MC_FLAG_ORDER_Z /
+    MC_FLAG_ORDER_MIDDLE_OUT) the whole grid's codes and vertices are the same bytes, and the default's."""
+    eq, step = EQ["eq3"], step_of(512)
+    base = mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES
+    crcs = []
+    for f in (mc.FLAG_ORDER_Z, mc.FLAG_ORDER_MIDDLE_OUT, 0, mc.FLAG_ORDER_MIDDLE_OUT | mc.FLAG_TILE63):
+        r = ctx.march(eq, step, flags=base | f)
+        assert r.n_cells == 513 ** 3 and abs(r.n_tris / (38388 * 16) - 1) < 0.01      # SURVEY section 4: 38 388 at 128, x4 per doubling
+        crcs.append((r.n_tris, r.n_active, zlib.crc32(r.codes().tobytes()), zlib.crc32(r.vertices().tobytes())))
+    assert len(set(crcs)) == 1, crcs
+
+
+GOURSAT_32 = {-0.7: 1984, -0.5: 13024, -0.4: 16912, -0.3: 16144, -0.1: 5728}   # SURVEY 8d [probe]: the reference at grid_res 32
+
+
+def test_goursat_512_iso_sweep_through_the_captured_graph(mc, orc):
+    """BASELINE config 5 as stated: the 513^3 Goursat sweep replayed from ONE captured hipGraph with five iso values.  Every
+    frame's count scales from the reference's own counts at grid_res 32 (x4 per doubling, 4 doublings); the frame replayed
+    is the frame marched (same bytes); and a thin slab of two frames -- cut out of the whole-grid result by the triangle
+    offset of the layers below it -- equals the oracle's sweep of those layers bit for bit (positions) / 1e-6 (normals)."""
+    eq, step = EQ["goursat"], step_of(512)
+    c = mc.Context(0)
+    try:
+        c.graph_build(eq, step, iso=-0.4, flags=mc.FLAG_NORMALS)
+        for iso, n32 in GOURSAT_32.items():
+            g = c.graph_replay(iso)
+            assert g.n_cells == 513 ** 3
+            assert abs(g.n_tris / (n32 * 256) - 1) < 0.03, (iso, g.n_tris, n32 * 256)
+            if iso in (-0.4, -0.7):
+                gv = g.vertices()
+                zb, ze = (100, 103) if iso == -0.4 else (436, 439)
+                below = c.march(eq, step, iso, flags=mc.FLAG_NO_EMIT, z_begin=0, z_end=zb).n_tris
+                o = orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=7, z_begin=zb, z_end=ze)
+                assert o.n_tris > 0
+                part = gv[below:below + o.n_tris]
+                assert_same_floats(part[:, :, :3], o.soup, f"graph frame iso {iso}, layers {zb}..{ze}")
+                assert np.nanmax(np.abs(part[:, :, 3:] - o.normals)) <= TOL_NRM
+                m = c.march(eq, step, iso, flags=mc.FLAG_NORMALS)
+                assert m.n_tris == g.n_tris and zlib.crc32(m.vertices().tobytes()) == zlib.crc32(gv.tobytes())
+                c.graph_build(eq, step, iso=-0.4, flags=mc.FLAG_NORMALS)   # (the marches above re-targeted the context's buffers)
     finally:
         c.close()

@@ -206,3 +206,153 @@ def test_bench_in_flight_sweeps_produce_the_same_counts():
         assert j["config"]["in_flight"] == int(d)
         tris.add(j["config"]["triangles"])
     assert len(totals) == 1 and len(tris) == 1
+
+
+# ---- the multi-device entry points of the C ABI (mc_march_sharded, mc_comm_*: include/mc_hip.h) ----------------------
+SHARDED_CALLER = ROOT / "tests" / "native" / "sharded_caller"
+
+
+def build_sharded_caller(mc):
+    """tests/native/sharded_caller.cpp: a reference-style caller (the reference's #include lines, include/compat) that gives
+    its Marching object a device list."""
+    src = ROOT / "tests" / "native" / "sharded_caller.cpp"
+    if not SHARDED_CALLER.exists() or SHARDED_CALLER.stat().st_mtime < max(src.stat().st_mtime, (ROOT / "include" / "mc_marching.hpp").stat().st_mtime,
+                                                                            mc.LIB_PATH.stat().st_mtime):
+        subprocess.run(["g++", "-std=c++14", "-O1", f"-I{ROOT / 'include' / 'compat'}", str(src), "-o", str(SHARDED_CALLER),
+                        f"-L{mc.LIB_PATH.parent}", "-lmc_hip", f"-Wl,-rpath,{mc.LIB_PATH.parent}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return SHARDED_CALLER
+
+
+def test_sharded_caller_compiles_against_the_facade(mc):
+    assert build_sharded_caller(mc).exists()
+
+
+def test_c_shard_layers_is_the_python_rule(mc):
+    """mc_shard_layers (C ABI, what mc_march_sharded / mc_march_rank cut by) == shard_layers (the host logic the gloo tests run)."""
+    import ctypes as C
+    L = mc.lib()
+    for n in (0, 1, 5, 33, 257, 1025, 2001):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                a, b = C.c_int(), C.c_int()
+                L.mc_shard_layers(n, world, r, C.byref(a), C.byref(b))
+                assert (a.value, b.value) == mc.shard_layers(n, world, r)
+
+
+def test_sharded_entry_points_refuse_bad_arguments_without_a_gpu(mc):
+    """Argument checks come before any device work: an empty list, a null context, descending bounds."""
+    import ctypes as C
+    L = mc.lib()
+    p = mc.McParams()
+    p.equation, p.step, p.scale, p.z_end = b"x+y", 0.25, (C.c_float * 3)(1, 1, 1), -1
+    res, sh = (mc.McResult * 2)(), (mc.McShard * 2)()
+    arr = (C.c_void_p * 2)(None, None)
+    assert L.mc_march_sharded(arr, 0, C.byref(p), None, res, sh) == mc.MC_ERR_ARG
+    assert L.mc_march_sharded(arr, 2, C.byref(p), None, res, sh) == mc.MC_ERR_ARG and b"null" in L.mc_last_error()
+    assert L.mc_copy_sharded_vertices(arr, 2, None, 0) == mc.MC_ERR_ARG
+    assert L.mc_comm_create(None, None, 1, 0, C.byref(C.c_void_p())) == mc.MC_ERR_ARG
+    assert L.mc_march_rank(None, C.byref(p), None, None, None) == mc.MC_ERR_ARG
+
+
+@pytest.mark.gpu
+def test_reference_style_caller_with_a_device_list(mc):
+    """Marching::set_devices({0, 0, ...}) -- 2, 3, 4 and 8 slabs on the one GPU -- hands out the single sweep's Poly_Data and
+    soup bit for bit (five surfaces, one with a constraint and anisotropic scale, one lying in the lattice planes); seed
+    mode over two slabs is refused.  All in C++ through the facade and the C ABI."""
+    r = subprocess.run([str(build_sharded_caller(mc))], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_march_sharded_equals_the_whole_sweep(mc, ctx, orc, n):
+    """mc_march_sharded over a device list [0] * n: codes, soup (with normals) and -- MC_FLAG_INDEXED -- one Poly_Data equal
+    the single sweep's bytes, which equal the oracle's; the slabs' offsets are the prefix sums of their counts; caller-chosen
+    bounds (uneven, one EMPTY slab) give the same mesh."""
+    import numpy as np
+    eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(64))
+    whole = ctx.march(eq, step)
+    wv, wc = whole.vertices(), whole.codes()
+    o = orc.march(eq, step, pow_mode=orc.POW_EXACT, want=7)
+    assert np.array_equal(wc, o.codes) and np.array_equal(wv[:, :, :3].view(np.uint32), o.soup.view(np.uint32))
+    sh = mc.Sharded([0] * n)
+    try:
+        n1 = mc.cells_per_axis(step)
+        for bounds in (None, [0] + [n1 // 3] * (n - 1) + [n1]):    # near-equal slabs; uneven ones with n - 2 EMPTY slabs in the middle
+            r = sh.march(eq, step, bounds=bounds)
+            assert r.n_tris == whole.n_tris == o.n_tris and r.n_cells == whole.n_cells
+            assert np.array_equal(r.codes(), wc)
+            assert np.array_equal(r.vertices().view(np.uint32), wv.view(np.uint32))
+            acc = 0
+            for s, slab in zip(r.shards, r.slabs):
+                assert s.tri_offset == acc and s.n_tris_total == whole.n_tris and (s.z_begin, s.z_end) == (slab.z_begin, slab.z_end)
+                acc += slab.n_tris
+            ri = sh.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT, bounds=bounds)
+            wi = ctx.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NO_EMIT)
+            v, t, nrm = ri.indexed()
+            wvl, wtl, wn = wi.indexed()
+            assert (ri.n_verts, ri.n_tris) == (wi.n_verts, wi.n_tris)
+            assert np.array_equal(v.view(np.uint32), wvl.view(np.uint32)) and np.array_equal(t, wtl)
+            assert np.array_equal(nrm.view(np.uint32), wn.view(np.uint32))
+            assert ri.shards[-1].n_verts_total == wi.n_verts and ri.shards[0].vert_offset == 0
+    finally:
+        sh.close()
+
+
+@pytest.mark.gpu
+def test_march_sharded_headline_grid_counts(mc):
+    """The 1025^3 sphere over a device list of 8 on the one GPU: the reference-scaled counts (x4 per
+    doubling from 617 180 at 256) and slab offsets that tile the triangle list."""
+    import numpy as np
+    sh = mc.Sharded([0] * 8)
+    try:
+        r = sh.march("x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(1024)), flags=mc.FLAG_NORMALS)
+        assert r.n_cells == 1025 ** 3 and r.n_tris == 9881660
+        assert [s.tri_offset for s in r.shards] == list(np.cumsum([0] + [x.n_tris for x in r.slabs[:-1]]))
+        assert all(x.n_tris > 1_000_000 for x in r.slabs)        # (a sphere's zones of equal height have equal area)
+    finally:
+        sh.close()
+
+
+@pytest.mark.gpu
+def test_march_sharded_reports_the_failing_slab(mc):
+    import numpy as np
+    sh = mc.Sharded([0, 0])
+    try:
+        with pytest.raises(mc.McError) as e:
+            sh.march("x+", 0.25)
+        assert e.value.code == mc.MC_ERR_EVAL and "slab" in str(e.value)
+        with pytest.raises(mc.McError) as e:
+            sh.march("x+y", 0.25, bounds=[0, 7, 3])
+        assert e.value.code == mc.MC_ERR_ARG
+    finally:
+        sh.close()
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_with_one_rank(mc, ctx):
+    """mc_comm_* on the hardware there is: a world of ONE rank goes through librccl (dlopen, ncclGetUniqueId,
+    ncclCommInitRank, ncclAllGather on the side stream) -- mc_march_rank's result is the whole sweep with offsets 0, and the
+    asynchronous gather of a replayed graph's device-side counts returns that sweep's counts.  (More ranks than GPUs cannot
+    share a device under RCCL; the N-rank logic is the gloo tests' above.)"""
+    import numpy as np
+    eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(48))
+    comm = mc.Comm(ctx, mc.Comm.new_id(), 1, 0)
+    try:
+        whole = ctx.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
+        wv, wt, _ = whole.indexed()
+        r, s = comm.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
+        assert (r.n_tris, r.n_verts) == (whole.n_tris, whole.n_verts) and (s.tri_offset, s.vert_offset) == (0, 0)
+        assert (s.n_tris_total, s.n_verts_total) == (whole.n_tris, whole.n_verts)
+        v, t, _ = r.indexed()
+        assert np.array_equal(v.view(np.uint32), wv.view(np.uint32)) and np.array_equal(t, wt)
+        ctx.graph_build(eq, step, flags=mc.FLAG_NORMALS | mc.FLAG_NO_TIMING)
+        g = ctx.graph_replay(0.0)
+        for _ in range(5):
+            ctx.graph_replay_async(0.0)
+            comm.gather_async(g.d_totals)
+        counts = comm.wait()
+        ctx.graph_wait()
+        assert counts.shape == (1, 2) and int(counts[0, 0]) == whole.n_tris and int(counts[0, 1]) == whole.n_active
+    finally:
+        comm.close()

@@ -219,6 +219,59 @@ def test_gyroid_512_slabs_and_properties(mc, ext):
 
 
 @pytest.mark.gpu
+def test_gyroid_1024_whole_grid_properties(mc, orc, ext):
+    """BASELINE config 4 whole: 1025^3 cells, 40.8 M triangles (2.9 GB of vertices).  Size-independent properties of the one
+    sweep: eight Z slabs add up to it (counts) and concatenate to it (a checksum of checksums over the vertex bytes); three
+    layers cut out of it by the triangle offset of the layers below equal the oracle's sweep of those layers bit for bit;
+    on a sample, every vertex lies on a lattice edge (two lattice coordinates), on the surface (|f| small) and carries a
+    unit normal that points towards f > iso."""
+    import zlib
+    n, s = 1024, 12.566371
+    step = float(f32(2.0) / f32(n))
+    c = mc.Context(0)
+    try:
+        whole = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS)
+        n1, nt = whole.cells_per_axis, whole.n_tris
+        assert n1 == 1025 and whole.n_cells == 1025 ** 3 and 40_000_000 < nt < 42_000_000
+        v = whole.vertices()
+        # a thin slab of the whole against the oracle
+        zb, ze = 700, 703
+        below = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NO_EMIT, 0, zb).n_tris
+        o = orc.march(GYROID, step, 0.0, (s,) * 3, pow_mode=orc.POW_EXACT, want=7, z_begin=zb, z_end=ze)
+        part = v[below:below + o.n_tris]
+        assert np.array_equal(_u32(part[:, :, :3]), _u32(o.soup))
+        assert np.nanmax(np.abs(part[:, :, 3:] - o.normals)) <= 1e-6
+        # sample properties
+        smp = v[::4099].reshape(-1, 6)
+        ax = np.empty(n1 + 1, f32)
+        a = f32(-1.0)
+        for i in range(n1 + 1):
+            ax[i] = a
+            a = f32(a + f32(step))
+        on_lattice = np.isin(smp[:, :3], ax).sum(axis=1)
+        assert (on_lattice >= 2).all()
+        fval = c.eval_points(GYROID, (smp[:, :3] * f32(s)).astype(f32))
+        assert np.abs(fval).max() < 1e-3
+        assert np.abs(np.linalg.norm(smp[:, 3:], axis=1) - 1).max() < 1e-5
+        h = f32(1e-3)
+        fplus = c.eval_points(GYROID, ((smp[:, :3] + h * smp[:, 3:]) * f32(s)).astype(f32))
+        assert (fplus > fval).mean() > 0.999
+        # slabs == whole
+        at, tris, active = 0, 0, 0
+        for rank in range(8):
+            zb, ze = mc.shard_layers(n1, 8, rank)
+            r = c.march(GYROID, step, 0.0, (s,) * 3, mc.FLAG_NORMALS, zb, ze)
+            pv = r.vertices()
+            assert zlib.crc32(pv.tobytes()) == zlib.crc32(v[at:at + r.n_tris].tobytes()), rank
+            at += r.n_tris
+            tris += r.n_tris
+            active += r.n_active
+        assert (tris, active) == (nt, whole.n_active)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(12))
 def test_random_trig_expressions_match_the_oracle(mc, orc, ext, seed):
     rng = np.random.default_rng(7000 + seed)
