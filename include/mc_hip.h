@@ -77,9 +77,18 @@ enum {
                                /* cells, which shortens one sweep by 8-20 % and costs a batch 9 %.  The output  */
                                /* does not change                                                              */
     MC_FLAG_ORDER_Z = 8192u,   /* diagnostic: classify launches the slab's layers in z order ...                */
-    MC_FLAG_ORDER_MIDDLE_OUT = 16384u /* ... or from the slab's middle outwards (by default the library times  */
+    MC_FLAG_ORDER_MIDDLE_OUT = 16384u,/* ... or from the slab's middle outwards (by default the library times  */
                                /* both orders on an equation's first sweeps and keeps the faster); the output  */
                                /* must not change                                                              */
+    /* Cold start.  Evaluator::set_equation is instant in the reference (evaluator.cpp:15-17); specialising the kernels   */
+    /* for an equation takes hiprtc about a second.  By default the FIRST sweeps of an equation that neither this process */
+    /* nor $MC_JIT_CACHE has compiled run on an ahead-of-time build of the same kernels in which f is an interpreter of    */
+    /* the equation's DAG -- the same float operations in the same order, the same output bits -- while a host thread      */
+    /* compiles; later sweeps switch to the specialised kernels by themselves.  (Environment: MC_COLD_START=jit restores   */
+    /* "wait for hiprtc" process-wide.)                                                                                    */
+    MC_FLAG_INTERP = 32768u,   /* diagnostic: sweep with the interpreter build whatever is cached; the output must not  */
+                               /* change                                                                                 */
+    MC_FLAG_NO_INTERP = 65536u /* this sweep waits for the specialised kernels (what mc_graph_build always does)         */
 };
 #define MC_FLAG_LAYER_ORDER_MASK (MC_FLAG_ORDER_Z | MC_FLAG_ORDER_MIDDLE_OUT)
 
@@ -126,6 +135,8 @@ typedef struct mc_result {
                             /* a multi-GPU host exchange the counts (RCCL) without a host round trip  */
     int32_t emit_shared;    /* which emit kernel ran: 1 = mc_emit (vertices shared inside a chunk of   */
                             /* cells, the choice for expensive f), 0 = mc_emit_direct                  */
+    int32_t interpreted;    /* 1: this sweep ran on the interpreter build of the kernels (cold start,   */
+                            /* MC_FLAG_INTERP); 0: on the kernels specialised for the equation          */
 } mc_result;
 
 /* -- library ------------------------------------------------------------- */
@@ -161,6 +172,11 @@ size_t mc_expr_dump(const char *equation, char *buf, size_t cap);
  * as the device code, P1 power rule).  Used by the CPU-side tests of the compiler; the product
  * never calls it -- Evaluator::evaluate maps to mc_eval_points (GPU). */
 int mc_expr_debug_eval_host(const char *equation, float x, float y, float z, float *out);
+/* The same point through the PROGRAM the interpreter build of the kernels would run for this equation (MC_FLAG_INTERP and
+ * the cold-start note there): the DAG as one word per operation with liveness-allocated registers, walked on the host
+ * exactly as the device walks it.  MC_ERR_ARG when the equation does not fit the interpreter's tables (it then always
+ * waits for hiprtc).  CPU-side tests compare it with mc_expr_debug_eval_host bit for bit. */
+int mc_expr_debug_interp_host(const char *equation, float x, float y, float z, float *out);
 
 /* Specialise the kernels for `equation` with hiprtc (gfx950 code object) WITHOUT touching a GPU:
  * pre-populates the on-disk cache named by $MC_JIT_CACHE and lets a build machine check that the

@@ -24,6 +24,7 @@ FLAG_NORMALS, FLAG_KEEP_CODES, FLAG_NO_EMIT, FLAG_TILE1, FLAG_INDEXED, FLAG_NO_C
 FLAG_EMIT_DIRECT, FLAG_EMIT_SHARED, FLAG_SEAM, FLAG_TILE63 = 256, 512, 1024, 2048
 FLAG_BATCH = 4096   # several sweeps in flight (one context each): choose for throughput where that differs from the fastest single sweep
 FLAG_ORDER_Z, FLAG_ORDER_MIDDLE_OUT = 8192, 16384   # diagnostic: force classify's launch order of the layers
+FLAG_INTERP, FLAG_NO_INTERP = 32768, 65536           # cold start: sweep with the interpreter build / wait for hiprtc
 COMM_ID_BYTES = 128
 
 # every symbol include/mc_hip.h declares (checked by tests/test_abi.py)
@@ -34,7 +35,7 @@ ABI_SYMBOLS = [
     "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
     "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions", "mc_index_rebase",
     "mc_shard_layers", "mc_march_sharded", "mc_copy_sharded_vertices", "mc_copy_sharded_indexed", "mc_copy_sharded_codes",
-    "mc_comm_get_id", "mc_comm_create", "mc_comm_destroy", "mc_march_rank", "mc_comm_gather_async", "mc_comm_wait",
+    "mc_expr_debug_interp_host", "mc_comm_get_id", "mc_comm_create", "mc_comm_destroy", "mc_march_rank", "mc_comm_gather_async", "mc_comm_wait",
 ]
 
 
@@ -50,7 +51,7 @@ class McResult(C.Structure):
                 ("ms_classify", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
                 ("code_main_cells", C.c_int32), ("d_codes_tail", C.c_void_p),
                 ("n_verts", C.c_uint64), ("d_vertex_list", C.c_void_p), ("d_tri_list", C.c_void_p), ("d_vertex_normals", C.c_void_p),
-                ("ms_index", C.c_float), ("d_totals", C.c_void_p), ("emit_shared", C.c_int32)]
+                ("ms_index", C.c_float), ("d_totals", C.c_void_p), ("emit_shared", C.c_int32), ("interpreted", C.c_int32)]
 
 
 class McShard(C.Structure):
@@ -91,6 +92,7 @@ def lib():
         L.mc_expr_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.mc_expr_dump.restype = C.c_size_t
         L.mc_expr_debug_eval_host.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.mc_expr_debug_interp_host.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.mc_jit_precompile.argtypes = [C.c_char_p, C.POINTER(C.c_size_t)]
         L.mc_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mc_context_destroy.argtypes = [C.c_void_p]
@@ -167,6 +169,14 @@ def expr_dump(eq: str) -> str:
 def expr_debug_eval_host(eq: str, x, y, z) -> float:
     out = C.c_float()
     _check(lib().mc_expr_debug_eval_host(eq.encode(), x, y, z, C.byref(out)))
+    return out.value
+
+
+def expr_debug_interp_host(eq: str, x, y, z) -> float:
+    """The same point through the interpreter build's program for `eq`, walked on the host (raises McError when the equation
+    does not fit the interpreter's tables)."""
+    out = C.c_float()
+    _check(lib().mc_expr_debug_interp_host(eq.encode(), x, y, z, C.byref(out)))
     return out.value
 
 

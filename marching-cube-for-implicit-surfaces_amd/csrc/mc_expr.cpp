@@ -838,6 +838,122 @@ float eval_host(const Program& p, float x, float y, float z) {
 }  // namespace mc
 
 namespace mc {
+bool interp_program(const Program& p, InterpProg& out) {
+    memset(&out, 0, sizeof out);
+    const int n = (int)p.nodes.size();
+    if (n == 0 || p.root < 0) return false;
+    std::vector<int> last_use((size_t)n, -1), reg((size_t)n, -1);
+    last_use[(size_t)p.root] = n + 1;  // the result is never released
+    for (int i = n - 1; i >= 0; --i) {  // users come after their operands: one backward pass marks what the root reaches
+        if (last_use[(size_t)i] < 0) continue;
+        const Node& nd = p.nodes[(size_t)i];
+        if (nd.a >= 0 && last_use[(size_t)nd.a] < i) last_use[(size_t)nd.a] = i;
+        if (nd.b >= 0 && last_use[(size_t)nd.b] < i) last_use[(size_t)nd.b] = i;
+    }
+    uint32_t nconst = 0;
+    bool free_reg[MC_INTERP_REGS];
+    for (bool& f : free_reg) f = true;
+    auto operand = [&](int id, uint32_t& byte) -> bool {  // the operand byte of node `id` (mc_kernels.hip: McInterpProg::code)
+        const Node& nd = p.nodes[(size_t)id];
+        switch (nd.op) {
+        case NodeOp::VARX: byte = 64; return true;
+        case NodeOp::VARY: byte = 65; return true;
+        case NodeOp::VARZ: byte = 66; return true;
+        case NodeOp::CONST: {
+            uint32_t bits;
+            memcpy(&bits, &nd.cval, 4);
+            for (uint32_t k = 0; k < nconst; ++k) {
+                uint32_t have;
+                memcpy(&have, &out.cval[k], 4);
+                if (have == bits) {
+                    byte = 128 + k;
+                    return true;
+                }
+            }
+            if (nconst == MC_INTERP_CONSTS) return false;
+            out.cval[nconst] = nd.cval;
+            byte = 128 + nconst++;
+            return true;
+        }
+        default:
+            if (reg[(size_t)id] < 0) return false;
+            byte = (uint32_t)reg[(size_t)id];
+            return true;
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        const Node& nd = p.nodes[(size_t)i];
+        if (nd.op == NodeOp::CONST || nd.op == NodeOp::VARX || nd.op == NodeOp::VARY || nd.op == NodeOp::VARZ) continue;
+        if (last_use[(size_t)i] < 0) continue;  // (a node nothing uses: the builder leaves none, but it would cost a register)
+        uint32_t op, a = 0, b = 0;
+        switch (nd.op) {
+        case NodeOp::ADD: op = 0; break;
+        case NodeOp::SUB: op = 1; break;
+        case NodeOp::MUL: op = 2; break;
+        case NodeOp::DIV: op = 3; break;
+        case NodeOp::POW: op = 4; break;
+        case NodeOp::NEG: op = 5; break;
+        case NodeOp::SIN: op = 6; break;
+        case NodeOp::COS: op = 7; break;
+        case NodeOp::POWI: op = nd.ipow == 2 ? 8 : 9; break;
+        default: return false;
+        }
+        if (nd.a < 0 || !operand(nd.a, a)) return false;
+        if (op <= 4) {
+            if (nd.b < 0 || !operand(nd.b, b)) return false;
+        } else if (op == 9) {
+            if (nd.ipow < -32 || nd.ipow > 32) return false;
+            b = (uint32_t)(nd.ipow + 32);
+        }
+        // operands whose last use this is give their registers back BEFORE the result takes one (the interpreter fetches
+        // both operands before it writes)
+        if (nd.a >= 0 && last_use[(size_t)nd.a] == i && reg[(size_t)nd.a] >= 0) free_reg[reg[(size_t)nd.a]] = true;
+        if (nd.b >= 0 && last_use[(size_t)nd.b] == i && reg[(size_t)nd.b] >= 0) free_reg[reg[(size_t)nd.b]] = true;
+        int d = -1;
+        for (int k = 0; k < MC_INTERP_REGS; ++k)
+            if (free_reg[k]) {
+                d = k;
+                break;
+            }
+        if (d < 0 || out.n == MC_INTERP_MAXI) return false;
+        free_reg[d] = false;
+        reg[(size_t)i] = d;
+        out.code[out.n++] = op | ((uint32_t)d << 8) | (a << 16) | (b << 24);
+    }
+    // the result: the last operation's value, or -- f is a variable or a constant -- an operand byte
+    if (out.n == 0) return operand(p.root, out.root);
+    out.root = 64;  // (unused when n > 0)
+    return reg[(size_t)p.root] >= 0 && (out.code[out.n - 1] >> 8 & 0xFFu) == (uint32_t)reg[(size_t)p.root];
+}
+
+// mc_kernels.hip: mc_interp_run, statement for statement
+float interp_run_host(const InterpProg& P, float x, float y, float z) {
+    float r[MC_INTERP_REGS] = {0.0f};
+    auto fetch = [&](uint32_t o) -> float {
+        if (o < 64u) return r[o & (MC_INTERP_REGS - 1)];
+        if (o < 128u) return o == 64u ? x : o == 65u ? y : z;
+        return P.cval[(o - 128u) & (MC_INTERP_CONSTS - 1)];
+    };
+    volatile float last = fetch(P.root);
+    for (uint32_t i = 0; i < P.n; ++i) {
+        const uint32_t w = P.code[i];
+        const uint32_t op = w & 0xFFu, d = (w >> 8) & 0xFFu, ao = (w >> 16) & 0xFFu, bo = w >> 24;
+        volatile float a = fetch(ao), v;
+        if (op == 8u) v = a * a;
+        else if (op == 9u) v = pow_literal_int(a, (int)bo - 32);
+        else if (op == 5u) v = -a;
+        else if (op == 6u) v = mc_sinf(a);
+        else if (op == 7u) v = mc_cosf(a);
+        else {
+            volatile float b = fetch(bo);
+            v = op == 0u ? a + b : op == 1u ? a - b : op == 2u ? a * b : op == 3u ? a / b : pow_general(a, b);
+        }
+        r[d & (MC_INTERP_REGS - 1)] = v;
+        last = v;
+    }
+    return last;
+}
+
 int vector_op_cost(const Program& p) {
     int cost = 0;
     for (const Node& n : p.nodes) cost += node_cost(n);

@@ -92,6 +92,25 @@ bool finite_on_domain(const Program& p, double radius);
 // it: below a measured threshold recomputing a vertex for each of its ~6 output copies is cheaper than sharing it.
 int vector_op_cost(const Program& p);
 
+// ---- the DAG as a PROGRAM for the interpreter build of the kernels (mc_kernels.hip, MC_INTERP: what an equation's first
+// sweeps run on while hiprtc specialises the kernels for it).  Must match McInterpProg there.
+#define MC_INTERP_MAXI 120   // operations
+#define MC_INTERP_REGS 16    // live values
+#define MC_INTERP_CONSTS 64
+struct InterpProg {
+    uint32_t n, root, cons_op;
+    float cons_rhs;
+    uint32_t code[MC_INTERP_MAXI];  // op | dst << 8 | a << 16 | b << 24; operand byte: 0..63 register, 64 / 65 / 66 = x / y / z, 128 + k =
+                                    // constant k; ops: 0 + 1 - 2 * 3 / 4 pow 5 neg 6 sin 7 cos 8 square 9 literal-integer power (b = n + 32)
+    float cval[MC_INTERP_CONSTS];
+};
+static_assert(sizeof(InterpProg) == 16 + 4 * MC_INTERP_MAXI + 4 * MC_INTERP_CONSTS, "InterpProg layout");
+// One word per operation in topological order (the order emit_hip's lines have), values in registers allocated by
+// liveness, constants in a table.  false: the program does not fit the tables.
+bool interp_program(const Program& p, InterpProg& out);
+// The device interpreter's walk, on the host (diagnostic: mc_hip.h mc_expr_debug_interp_host).
+float interp_run_host(const InterpProg& P, float x, float y, float z);
+
 // Power rule P1 (shared by constant folding, eval_host and -- as generated code -- the device).
 float pow_literal_int(float a, int n);
 float pow_general(float a, float b);

@@ -95,6 +95,89 @@ __device__ __forceinline__ void mc_sin_iv(float l, float h, float& lo, float& hi
 __device__ __forceinline__ void mc_cos_iv(float l, float h, float& lo, float& hi) { mc_trig_iv(l, h, 0.0f, 1, lo, hi); }
 
 //@@MC_F_BEGIN  (replaced by generated code when JIT-compiled)
+#ifdef MC_INTERP
+// ------------------------------------------------------------------ the interpreter build (cold start)
+// Evaluator::set_equation is instant in the reference (evaluator.cpp:15-17); specialising this file for an equation takes
+// hiprtc about a second.  So the library also carries this file compiled AHEAD of time with f as an INTERPRETER of the same
+// DAG (build.py: -DMC_INTERP): the first sweeps of an equation nobody has compiled yet run on it while a host thread
+// compiles the specialised kernels (mc_runtime.hip: get_compiled).  The program is the DAG in topological order, one word
+// per operation, in constant memory; every lane walks the same words, so the walk is scalar loads and uniform branches,
+// and the values live in a small register file indexed by uniform numbers.  The same float operations on the same
+// operands in the same order as the generated mc_f (no contraction in this build either): the same bits
+// (tests: MC_FLAG_INTERP).  What the interpreter build does not have is everything that is generated PER equation beside
+// mc_f -- enclosures (it takes the sampling walk), staged / tabulated forms -- and the finiteness proof (it keeps the NaN
+// bookkeeping).
+#define MC_INTERP_MAXI 120   // operations of one program
+#define MC_INTERP_REGS 16    // live values (the host allocates registers by liveness: mc_runtime.hip, interp_program)
+#define MC_INTERP_CONSTS 64
+struct McInterpProg {
+    u32 n;        // operations
+    u32 root;     // the result's operand byte when n == 0 (f is a variable or a constant)
+    u32 cons_op;  // constraint programs: 0 '>=', 1 '<=', 2 '>', 3 '<'
+    float cons_rhs;
+    u32 code[MC_INTERP_MAXI];  // op | dst << 8 | a << 16 | b << 24; operand byte: 0..63 register, 64 / 65 / 66 = x / y / z,
+                               // 128 + k = constant k; POWI: b = exponent + 32
+    float cval[MC_INTERP_CONSTS];
+};
+struct McInterpAll {
+    u32 ncons, pad[3];
+    McInterpProg f, g[3];  // f and the left-hand sides of the enabled constraints
+};
+__device__ __constant__ McInterpAll c_interp;
+
+__device__ __forceinline__ float mc_pow_int_rt(float a, int n) {  // mc_pow_int<N> with N at run time: the same chain
+    const int m = n < 0 ? -n : n;
+    const double p = (double)a;
+    double r = p;
+    for (int i = 2; i <= m; ++i) r = r * p;
+    if (n < 0) r = 1.0 / r;
+    return (float)r;
+}
+__device__ __forceinline__ float mc_interp_run(const McInterpProg& P, float x, float y, float z) {
+    float r[MC_INTERP_REGS];
+#pragma unroll
+    for (int i = 0; i < MC_INTERP_REGS; ++i) r[i] = 0.0f;
+    auto fetch = [&](u32 o) -> float {
+        if (o < 64u) return r[o & (MC_INTERP_REGS - 1)];
+        if (o < 128u) return o == 64u ? x : o == 65u ? y : z;
+        return P.cval[(o - 128u) & (MC_INTERP_CONSTS - 1)];
+    };
+    float last = fetch(P.root);
+    const u32 n = P.n;
+    for (u32 i = 0; i < n; ++i) {
+        const u32 w = P.code[i];
+        const u32 op = w & 0xFFu, d = (w >> 8) & 0xFFu, ao = (w >> 16) & 0xFFu, bo = w >> 24;
+        const float a = fetch(ao);
+        float v;
+        if (op == 8u) v = a * a;                                   // POWI 2
+        else if (op == 9u) v = mc_pow_int_rt(a, (int)bo - 32);     // POWI n
+        else if (op == 5u) v = -a;
+        else if (op == 6u) v = mc_sinf(a);
+        else if (op == 7u) v = mc_cosf(a);
+        else {
+            const float b = fetch(bo);
+            v = op == 0u ? a + b : op == 1u ? a - b : op == 2u ? a * b : op == 3u ? a / b : mc_pow_general(a, b);
+        }
+        r[d & (MC_INTERP_REGS - 1)] = v;
+        last = v;
+    }
+    return last;
+}
+__device__ __forceinline__ float mc_f(float x, float y, float z) { return mc_interp_run(c_interp.f, x, y, z); }
+#define MC_CONS 1
+// marching.cpp:255-280 check_constraints at a (scaled) point; NaN fails, as in C++
+__device__ __forceinline__ bool mc_ok(float x, float y, float z) {
+    bool ok = true;
+    const u32 nc = c_interp.ncons;
+    for (u32 i = 0; i < nc; ++i) {
+        const float g = mc_interp_run(c_interp.g[i], x, y, z);
+        const u32 op = c_interp.g[i].cons_op;
+        const float rhs = c_interp.g[i].cons_rhs;
+        ok = ok & (op == 0u ? g >= rhs : op == 1u ? g <= rhs : op == 2u ? g > rhs : g < rhs);
+    }
+    return ok;
+}
+#else
 __device__ __forceinline__ float mc_f(float x, float y, float z) {
     const float t0 = z * z;
     const float t1 = t0 - 1.0f;
@@ -123,6 +206,7 @@ __device__ __forceinline__ void mc_ok_iv(float xl, float xh, float yl, float yh,
     dead = !(xh > -0.5f);
 }
 #endif
+#endif  // MC_INTERP
 //@@MC_F_END
 
 // ------------------------------------------------------------------ parameters

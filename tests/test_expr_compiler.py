@@ -136,3 +136,57 @@ def test_integer_power_of_a_subexpression_generates_valid_code(mc):
         import re
         assert not re.search(r"= t\d+t\d+\)", src), src
         assert mc.jit_precompile(eq) > 0
+
+
+# ---- the interpreter's program (cold start: mc_hip.h MC_FLAG_INTERP) -------------------------------------------------
+def test_interpreter_program_matches_the_dag(mc, orc):
+    """The first sweeps of an equation run on an interpreter of its DAG (mc_kernels.hip MC_INTERP): one word per operation,
+    16 registers allocated by liveness, a constant table.  Walked on the host exactly as the device walks it
+    (mc_expr_debug_interp_host) it gives the DAG's value -- and the oracle's stack walk's -- bit for bit: register reuse,
+    shared sub-expressions, constants folded or not, roots that are a bare variable or literal."""
+    rng = random.Random(4242)
+    pts = [tuple(float(np.float32(rng.uniform(-1.5, 1.5))) for _ in range(3)) for _ in range(5)] + [(0.0, 1.0, -1.0)]
+    n_ok = 0
+    for k in range(1500):
+        eq = _random_expr(rng) if k % 3 else "+".join(_random_expr(rng) for _ in range(rng.randint(2, 6)))   # (long sums: many live values)
+        if not mc.expr_check(eq) or mc.expr_validate(eq) != mc.MC_OK:
+            continue
+        for p in pts:
+            want = mc.expr_debug_eval_host(eq, *p)
+            try:
+                got = mc.expr_debug_interp_host(eq, *p)
+            except mc.McError as e:        # does not fit the tables: allowed, but must say so
+                assert e.code == mc.MC_ERR_ARG and "too long" in str(e), eq
+                break
+            assert same(got, want), (eq, p, got, want)
+            ref = orc.evaluate(eq, *p, pow_mode=orc.POW_EXACT)
+            assert ref is None or same(got, ref), (eq, p, got, ref)
+        else:
+            n_ok += 1
+    assert n_ok > 900
+    for eq in ("x", "5", "(y)", "-z", "2x", "x^0", "x^1"):
+        assert same(mc.expr_debug_interp_host(eq, 0.5, -0.25, 2.0), mc.expr_debug_eval_host(eq, 0.5, -0.25, 2.0)), eq
+
+
+@pytest.mark.parametrize("name", sorted(EQ))
+def test_interpreter_program_example_equations(mc, name):
+    rng = np.random.default_rng(11)
+    for p in rng.uniform(-1.2, 1.2, size=(100, 3)).astype(np.float32):
+        p = tuple(map(float, p))
+        assert same(mc.expr_debug_interp_host(EQ[name], *p), mc.expr_debug_eval_host(EQ[name], *p)), (name, p)
+
+
+def test_interpreter_refuses_what_does_not_fit(mc):
+    """More than 16 values alive at once, or more than 120 operations: the equation then always waits for hiprtc
+    (mc_runtime.hip get_compiled falls back), and the diagnostic entry says why."""
+    wide = "(" + ")*(".join(f"x^{k}+y^{k + 1}" for k in range(2, 14)) + ")"          # fits
+    assert np.isfinite(mc.expr_debug_interp_host(wide, 0.5, 0.25, 0.125))
+    # a right-nested chain keeps every left operand alive until the innermost bracket is done
+    deep = "*(".join(f"(x^{k % 7 + 2}*y-{k}.5)" for k in range(20)) + "*(z" + ")" * 20
+    assert mc.expr_validate(deep) == mc.MC_OK
+    with pytest.raises(mc.McError) as e:
+        mc.expr_debug_interp_host(deep, 0.5, 0.25, 0.125)
+    assert e.value.code == mc.MC_ERR_ARG
+    long = "+".join(f"x^{k % 5 + 2}*{k}.25" for k in range(70))
+    with pytest.raises(mc.McError):
+        mc.expr_debug_interp_host(long, 0.5, 0.25, 0.125)
