@@ -388,7 +388,50 @@ def main():
     # clears the counts).  Only the fence at the end of the timed region waits for anything.
     lib_streams = sides = totals_devs = slots = None
     exchange_note = None
-    if multi and cdev == "cuda" and not args.no_graph:
+    # The exchange itself is the LIBRARY's (mc_comm_*: ncclAllGather through the RCCL the process has loaded, on a side stream
+    # behind the sweep -- what a C++ caller with one process per GPU uses, include/mc_hip.h): one communicator per in-flight
+    # context, their ids made by rank 0 and broadcast over the process group torch.distributed.run set up.  It is rehearsed
+    # once before the timed steps and every rank must agree that it works; otherwise (or with BENCH_EXCHANGE=torch) the
+    # same exchange goes through torch.distributed's all_gather_into_tensor as in rounds 1-3.
+    comms = d_totals = None
+    if multi and cdev == "cuda" and not args.no_graph and os.environ.get("BENCH_EXCHANGE", "library") == "library":
+        ok = 1
+        try:
+            nb = mc_amd.COMM_ID_BYTES
+            ids = torch.zeros(depth * nb + 1, dtype=torch.uint8, device=cdev)
+            if rank == 0:
+                try:
+                    raw = b"".join(mc_amd.Comm.new_id() for _ in ctxs) + b"\x01"
+                    ids.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+                except Exception as e:  # noqa: BLE001 -- e.g. librccl.so cannot be loaded: every rank learns it from the flag byte
+                    exchange_note = f"torch (mc_comm_get_id failed: {e})"[:200]
+            dist.broadcast(ids, 0)
+            raw = ids.cpu().numpy().tobytes()
+            if raw[-1] != 1:
+                raise RuntimeError("rank 0 could not make a communicator id")
+            comms = [mc_amd.Comm(c, raw[k * nb:(k + 1) * nb], world, rank) for k, c in enumerate(ctxs)]
+            d_totals = [int(c.graph_replay(0.0).d_totals) for c in ctxs]
+            for k, c in enumerate(ctxs):     # rehearsal: one replay + gather per context, checked against the host's count
+                c.graph_replay_async(0.0)
+                comms[k].gather_async(d_totals[k])
+            for k, c in enumerate(ctxs):
+                got = comms[k].wait()
+                if int(got[rank, 0]) != int(c.graph_wait().n_tris):
+                    raise RuntimeError(f"gathered count {int(got[rank, 0])} is not this rank's")
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            exchange_note = exchange_note or f"torch (library exchange failed: {type(e).__name__}: {e})"[:200]
+        agree = torch.tensor([ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            for cm in comms or []:
+                try:
+                    cm.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            comms = None
+            exchange_note = exchange_note or "torch (another rank could not set the library exchange up)"
+    if multi and cdev == "cuda" and not args.no_graph and comms is None:
         def raw_totals(c):   # zero-copy view of a context's {n_tris, n_active} words (same address sweep after sweep)
             class _Raw:
                 __cuda_array_interface__ = {"shape": (2,), "typestr": "<i8", "data": (int(c.graph_replay(0.0).d_totals), False), "version": 2}
@@ -412,7 +455,9 @@ def main():
         else:
             r = None
             c.graph_replay_async(0.0)
-        if multi:
+        if multi and comms is not None:
+            comms[i % depth].gather_async(d_totals[i % depth])
+        elif multi:
             if totals_devs is not None:
                 lib_stream, side, totals_dev = lib_streams[i % depth], sides[i % depth], totals_devs[i % depth]
                 side.wait_stream(lib_stream)
@@ -434,6 +479,12 @@ def main():
         for wk in pending:
             wk.wait()
         pending.clear()
+        if comms is not None and step_no[0] > 0:
+            last = (step_no[0] - 1) % depth
+            for k, cm in enumerate(comms):
+                got = cm.wait()
+                if k == last:
+                    counts_dev.copy_(torch.from_numpy(got[:, 0].astype(np.int64)))
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -530,7 +581,9 @@ def main():
                                   "in flight, each with its own buffers and stream), counts read once"),
                        "in_flight": depth,
                        "ms_per_step_one_in_flight": round(serial_ms, 4) if serial_ms is not None else None,
-                       "count_exchange": (None if not multi else "rccl all_gather_into_tensor, device-side counts" if totals_devs is not None
+                       "count_exchange": (None if not multi else
+                                          "library: mc_comm_gather_async (ncclAllGather over RCCL, side stream), device-side counts" if comms is not None
+                                          else "rccl all_gather_into_tensor, device-side counts" + (f" [{exchange_note}]" if exchange_note else "") if totals_devs is not None
                                           else (exchange_note or "all_gather_into_tensor through the host")),
                        "z_bounds": bounds if world > 1 else None},
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
@@ -581,6 +634,8 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cold_start"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(out), flush=True)
+    for cm in comms or []:
+        cm.close()
     for c in ctxs:
         c.close()
     if multi:

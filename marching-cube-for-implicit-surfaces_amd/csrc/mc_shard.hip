@@ -73,12 +73,20 @@ Rccl* rccl() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {getenv("MC_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* nm : names) {
-            if (!nm || !*nm) continue;
-            R.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        // A process that has RCCL loaded already (torch.distributed brings its own copy, soname librccl.so.1) must not
+        // get a second one: two copies would resolve each other's internals.  So: the loaded copy if there is one, else
+        // $MC_RCCL_LIB / the ROCm installation's, bound to its own symbols.
+        const char* loaded[] = {"librccl.so.1", "librccl.so"};
+        for (const char* nm : loaded) {
+            R.so = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
             if (R.so) break;
-            R.why = dlerror();
+        }
+        const char* names[] = {getenv("MC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names) {
+            if (R.so) break;
+            if (!nm || !*nm) continue;
+            R.so = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+            if (!R.so) R.why = dlerror();
         }
         if (!R.so) return;
         R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.so, "ncclGetUniqueId");

@@ -161,7 +161,14 @@ def test_bench_rccl_path_with_one_rank():
                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["config"]["triangles"] == 617180 and d["config"]["count_exchange"] == "rccl all_gather_into_tensor, device-side counts"
+    assert d["n_gpus"] == 1 and d["config"]["triangles"] == 617180
+    assert d["config"]["count_exchange"].startswith("library: mc_comm_gather_async"), d["config"]["count_exchange"]
+    # ... and the torch.distributed form of the same exchange, which bench.py falls back to when the library's cannot be set up
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--grid-res", "256",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=dict(env, BENCH_EXCHANGE="torch", MASTER_PORT="29543"), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["triangles"] == 617180 and d["config"]["count_exchange"] == "rccl all_gather_into_tensor, device-side counts"
 
 
 def test_rebalance_layers_equalises_a_known_cost_profile():
