@@ -225,11 +225,12 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     torch.cuda.synchronize()
     dt1 = time.perf_counter() - t1
     assert tris1 == tris
-    # per-kernel times: the same frames once more, one at a time, from a capture that carries the hipEvent nodes
-    ctx.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | t63)
+    # per-kernel times: the same frames once more, one at a time and kernel by kernel (mc_march), each kernel timed by the
+    # start / stop timestamps of its own dispatch -- the figures rocprofv3's kernel trace reports, not event nodes that also
+    # see the gaps between a graph's nodes (for kernels under 100 us those gaps were 10-55 % of the figure)
     kt = np.zeros(4)
     for iso in isos:
-        r = ctx.graph_replay(float(iso))
+        r = ctx.march(eq, step, float(iso), flags=mc_amd.FLAG_NORMALS | t63)
         kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
     kt /= frames
     n1 = mc_amd.cells_per_axis(step)
@@ -246,7 +247,8 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
                       "ms_per_step_one_in_flight": round(dt1 / frames * 1e3, 4), "mtris_per_s_one_in_flight": round(tris / dt1 / 1e6, 2),
                       "kernel_ms": {"classify": round(kt[0], 4), "scan": round(kt[1], 4), "emit": round(kt[2], 4), "gpu_total": round(kt[3], 4),
                                     "emit_kernel": "mc_emit" if r.emit_shared else "mc_emit_direct",
-                                    "source": "HIP events of the same frames replayed one at a time behind the timed region"},
+                                    "source": "start / stop timestamps of each kernel's own dispatch (hipExtModuleLaunchKernel events), the same "
+                                              "frames swept one at a time behind the timed region"},
                       "roofline": {"bound": "hbm", "kernel": "mc_classify", "achieved": round(cells / (kt[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(cells / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "traffic": pmc_traffic("mc_classify", "goursat512" if n == 512 else None),
@@ -525,14 +527,12 @@ def main():
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
         ctx1.close()
 
-    # per-kernel GPU times for the roofline: the same K sweeps again, replayed one by one from a capture that carries the
-    # hipEvent nodes (events are read on the host, so these replays are synchronous; right behind the timed region, same
-    # process, same buffers)
+    # per-kernel GPU times for the roofline: the same K sweeps again, one at a time and kernel by kernel (mc_march), each
+    # kernel timed by the start / stop timestamps of its own dispatch (hipExtModuleLaunchKernel events, on the library's
+    # stream) -- the figures rocprofv3 --kernel-trace reports; right behind the timed region, same process, same buffers
     kt = np.zeros(4)
-    if not args.no_graph:
-        ctx.graph_build(eq, step, 0.0, scale, flags, zb, ze)
     for _ in range(args.steps):
-        rk = ctx.graph_replay(0.0) if not args.no_graph else ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
+        rk = ctx.march(eq, step, 0.0, scale, flags=flags, z_begin=zb, z_end=ze)
         kt += (rk.ms_classify, rk.ms_scan, rk.ms_emit, rk.ms_total)
     kt /= max(args.steps, 1)
 
@@ -589,7 +589,8 @@ def main():
             "mtris_per_s": round(tris / (elapsed / args.steps) / 1e6, 3),
             "kernel_ms": {"classify": round(ms_cls, 4), "scan": round(ms_scan, 4), "emit": round(ms_emit, 4),
                           "gpu_total": round(ms_tot, 4), "emit_kernel": emit_kernel,
-                          "source": f"HIP events of {args.steps} synchronous replays right behind the timed region"},
+                          "source": f"start / stop timestamps of each kernel's own dispatch (hipExtModuleLaunchKernel events) in {args.steps} "
+                                    "sweeps launched one at a time right behind the timed region"},
             # `roofline` is the DOMINANT kernel's (the one with the longer HIP-event time); the other one follows as
             # `second_roofline`.  classify: 1 B per cell written.  emit: what it must write (72 B per triangle); SURVEY 8d also
             # books 1 B/cell of code reads to it, which the record design never performs -- that byte only appears in the

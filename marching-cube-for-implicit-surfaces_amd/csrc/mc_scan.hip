@@ -31,9 +31,11 @@ typedef unsigned char u8;
 // written by one agent-scope store (the value travels with its tag: no fence, MI355X_MICROARCH.md "granule"); a reader
 // accepts a pair only when both words carry the same non-zero state (the words are written in order, first to second,
 // and read in the same order, so a torn pair shows two different states).  `status` and `ticket` are zero when the kernel
-// starts (the host clears the control block once; every sweep leaves it clean, see below).  Spins are bounded: a workgroup that gives up raises totals[3] (the
-// host reads totals[3] from the device copy only when the counts look wrong -- it cannot happen while every workgroup
-// with a lower ticket is running, which the ticket order guarantees).
+// starts (the host clears the control block once; every sweep leaves it clean, see below).  Spins are bounded: a workgroup
+// that gives up raises totals[3], mirrored into the host's pinned totals like the counts, and the host checks that word
+// after EVERY sweep and every batch of replays (mc_runtime.hip: mc_march, graph_collect): a give-up is MC_ERR_HIP, never
+// silent offsets, and the context clears its control block before its next sweep.  (It cannot happen while every
+// workgroup with a lower ticket is running, which the ticket order guarantees.)
 #define SCAN_AGG 1ull
 #define SCAN_INC 2ull
 #define SCAN_SPIN_MAX (1u << 24)
