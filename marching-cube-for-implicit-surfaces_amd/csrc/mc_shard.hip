@@ -171,11 +171,17 @@ int mc_march_sharded(mc_context* const* ctxs, int n, const mc_params* p, const i
         if (rc[(size_t)i]) err[(size_t)i] = mc_last_error();  // (thread-local text: keep it for the caller's thread)
     };
     {
-        std::vector<std::thread> th;
-        th.reserve((size_t)n);
-        for (int i = 1; i < n; ++i) th.emplace_back(slab, i);
+        // one host thread per slab (64 MB stacks: a slab's first sweep of an equation may run hiprtc), slab 0 on the caller's
+        std::vector<McThread> th((size_t)n);
+        for (int i = 1; i < n; ++i) {
+            auto* fn = new std::function<void()>([&slab, i]() { slab(i); });
+            if (!mc_thread_start(th[(size_t)i], fn)) {
+                delete fn;
+                slab(i);  // (no thread to be had: the slab runs here, after slab 0's)
+            }
+        }
         slab(0);
-        for (auto& t : th) t.join();
+        for (int i = 1; i < n; ++i) mc_thread_join(th[(size_t)i]);
     }
     for (int i = 0; i < n; ++i)
         if (rc[(size_t)i]) return mc_internal_fail(rc[(size_t)i], "slab %d (layers [%d, %d)): %s", i, b[(size_t)i], b[(size_t)i + 1], err[(size_t)i].c_str());

@@ -13,6 +13,21 @@
 #include <string>
 #include <vector>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+// a crash in here must say where (the test shows this program's output): frames to stderr, then the default action
+static void on_crash(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "sharded_caller: fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 static bool same_bits(const std::vector<float>& a, const std::vector<float>& b) {
     return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0);
 }
@@ -36,6 +51,10 @@ static bool sweep(Marching& m, bool indexed, Mesh& out) {
 }
 
 int main(int argc, char** argv) {
+    signal(SIGSEGV, on_crash);
+    signal(SIGABRT, on_crash);
+    signal(SIGBUS, on_crash);
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     std::vector<int> base;
     if (argc > 1)
         for (const char* q = argv[1]; q && *q;) {

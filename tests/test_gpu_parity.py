@@ -826,19 +826,25 @@ GOURSAT_32 = {-0.7: 1984, -0.5: 13024, -0.4: 16912, -0.3: 16144, -0.1: 5728}   #
 
 def test_goursat_512_iso_sweep_through_the_captured_graph(mc, orc):
     """BASELINE config 5 as stated: the 513^3 Goursat sweep replayed from ONE captured hipGraph with five iso values.  Every
-    frame's count scales from the reference's own counts at grid_res 32 (x4 per doubling, 4 doublings); the frame replayed
-    is the frame marched (same bytes); and a thin slab of two frames -- cut out of the whole-grid result by the triangle
-    offset of the layers below it -- equals the oracle's sweep of those layers bit for bit (positions) / 1e-6 (normals)."""
+    frame replayed is the frame swept un-captured (same count; for two frames the same bytes); the counts scale from the
+    reference's own at grid_res 32 (x4 per doubling) where that coarse grid resolves the surface; and a thin slab of two
+    frames -- cut out of the whole-grid result by the triangle offset of the layers below it -- equals the oracle's sweep of
+    those layers bit for bit (positions) / 1e-6 (normals)."""
     eq, step = EQ["goursat"], step_of(512)
     c = mc.Context(0)
     try:
         c.graph_build(eq, step, iso=-0.4, flags=mc.FLAG_NORMALS)
         for iso, n32 in GOURSAT_32.items():
             g = c.graph_replay(iso)
-            assert g.n_cells == 513 ** 3
-            assert abs(g.n_tris / (n32 * 256) - 1) < 0.15, (iso, g.n_tris, n32 * 256)   # (a 33-cell grid is a coarse yardstick: 13 % off at iso -0.3)
-            if iso in (-0.4, -0.7):
-                gv = g.vertices()
+            assert g.n_cells == 513 ** 3 and g.interpreted == 0
+            # SURVEY 8d's counts at grid_res 32 scale by x4 per doubling where the 33-cell grid resolves the surface (within
+            # 15 % at iso -0.7 ... -0.3; at -0.1 the surface's thin parts are below that grid's resolution: half of x256)
+            assert abs(g.n_tris / (n32 * 256) - 1) < (0.15 if iso < -0.2 else 0.6), (iso, g.n_tris, n32 * 256)
+            gv = g.vertices() if iso in (-0.4, -0.7) else None
+            m = c.march(eq, step, iso, flags=mc.FLAG_NORMALS | mc.FLAG_NO_INTERP)      # (re-targets the context's buffers: gv is on the host by now)
+            assert (m.n_tris, m.n_active) == (g.n_tris, g.n_active), iso
+            if gv is not None:
+                assert zlib.crc32(m.vertices().tobytes()) == zlib.crc32(gv.tobytes())
                 zb, ze = (100, 103) if iso == -0.4 else (436, 439)
                 below = c.march(eq, step, iso, flags=mc.FLAG_NO_EMIT, z_begin=0, z_end=zb).n_tris
                 o = orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=7, z_begin=zb, z_end=ze)
@@ -846,8 +852,6 @@ def test_goursat_512_iso_sweep_through_the_captured_graph(mc, orc):
                 part = gv[below:below + o.n_tris]
                 assert_same_floats(part[:, :, :3], o.soup, f"graph frame iso {iso}, layers {zb}..{ze}")
                 assert np.nanmax(np.abs(part[:, :, 3:] - o.normals)) <= TOL_NRM
-                m = c.march(eq, step, iso, flags=mc.FLAG_NORMALS)
-                assert m.n_tris == g.n_tris and zlib.crc32(m.vertices().tobytes()) == zlib.crc32(gv.tobytes())
-                c.graph_build(eq, step, iso=-0.4, flags=mc.FLAG_NORMALS)   # (the marches above re-targeted the context's buffers)
+            # (the next replay finds its buffers re-targeted by the sweeps above and re-captures its own sweep first)
     finally:
         c.close()

@@ -225,7 +225,7 @@ def build_sharded_caller(mc):
     src = ROOT / "tests" / "native" / "sharded_caller.cpp"
     if not SHARDED_CALLER.exists() or SHARDED_CALLER.stat().st_mtime < max(src.stat().st_mtime, (ROOT / "include" / "mc_marching.hpp").stat().st_mtime,
                                                                             mc.LIB_PATH.stat().st_mtime):
-        subprocess.run(["g++", "-std=c++14", "-O1", f"-I{ROOT / 'include' / 'compat'}", str(src), "-o", str(SHARDED_CALLER),
+        subprocess.run(["g++", "-std=c++14", "-O1", "-g", "-rdynamic", f"-I{ROOT / 'include' / 'compat'}", str(src), "-o", str(SHARDED_CALLER),
                         f"-L{mc.LIB_PATH.parent}", "-lmc_hip", f"-Wl,-rpath,{mc.LIB_PATH.parent}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return SHARDED_CALLER
 
@@ -336,30 +336,43 @@ def test_march_sharded_reports_the_failing_slab(mc):
         sh.close()
 
 
+RCCL_ONE_RANK = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import mc_amd as mc
+ctx = mc.Context(0)
+eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(48))
+comm = mc.Comm(ctx, mc.Comm.new_id(), 1, 0)
+whole = ctx.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
+wv, wt, _ = whole.indexed()
+r, s = comm.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
+assert (r.n_tris, r.n_verts) == (whole.n_tris, whole.n_verts) and (s.tri_offset, s.vert_offset) == (0, 0)
+assert (s.n_tris_total, s.n_verts_total) == (whole.n_tris, whole.n_verts)
+v, t, _ = r.indexed()
+assert np.array_equal(v.view(np.uint32), wv.view(np.uint32)) and np.array_equal(t, wt)
+ctx.graph_build(eq, step, flags=mc.FLAG_NORMALS | mc.FLAG_NO_TIMING)
+g = ctx.graph_replay(0.0)
+for _ in range(70):                    # (more gathers than the communicator has slots: it drains and goes on)
+    ctx.graph_replay_async(0.0)
+    comm.gather_async(g.d_totals)
+counts = comm.wait()
+ctx.graph_wait()
+assert counts.shape == (1, 2) and int(counts[0, 0]) == whole.n_tris and int(counts[0, 1]) == whole.n_active
+comm.close()
+ctx.close()
+print("RCCL_ONE_RANK_OK", whole.n_tris)
+'''
+
+
 @pytest.mark.gpu
-def test_rccl_communicator_with_one_rank(mc, ctx):
+def test_rccl_communicator_with_one_rank(tmp_path):
     """mc_comm_* on the hardware there is: a world of ONE rank goes through librccl (dlopen, ncclGetUniqueId,
     ncclCommInitRank, ncclAllGather on the side stream) -- mc_march_rank's result is the whole sweep with offsets 0, and the
     asynchronous gather of a replayed graph's device-side counts returns that sweep's counts.  (More ranks than GPUs cannot
-    share a device under RCCL; the N-rank logic is the gloo tests' above.)"""
-    import numpy as np
-    eq, step = "x^2+y^2+z^2-1", float(np.float32(2.0) / np.float32(48))
-    comm = mc.Comm(ctx, mc.Comm.new_id(), 1, 0)
-    try:
-        whole = ctx.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
-        wv, wt, _ = whole.indexed()
-        r, s = comm.march(eq, step, flags=mc.FLAG_INDEXED | mc.FLAG_NORMALS)
-        assert (r.n_tris, r.n_verts) == (whole.n_tris, whole.n_verts) and (s.tri_offset, s.vert_offset) == (0, 0)
-        assert (s.n_tris_total, s.n_verts_total) == (whole.n_tris, whole.n_verts)
-        v, t, _ = r.indexed()
-        assert np.array_equal(v.view(np.uint32), wv.view(np.uint32)) and np.array_equal(t, wt)
-        ctx.graph_build(eq, step, flags=mc.FLAG_NORMALS | mc.FLAG_NO_TIMING)
-        g = ctx.graph_replay(0.0)
-        for _ in range(5):
-            ctx.graph_replay_async(0.0)
-            comm.gather_async(g.d_totals)
-        counts = comm.wait()
-        ctx.graph_wait()
-        assert counts.shape == (1, 2) and int(counts[0, 0]) == whole.n_tris and int(counts[0, 1]) == whole.n_active
-    finally:
-        comm.close()
+    share a device under RCCL; the N-rank logic is the gloo tests' above.)  In a process of its own, like an application
+    that starts, makes its communicator and sweeps."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(RCCL_ONE_RANK)
+    r = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
