@@ -196,7 +196,7 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     isos = np.linspace(-0.7, -0.1, frames).astype(np.float32)
     t63 = mc_amd.FLAG_TILE63 if os.environ.get("MC_FORCE63") == "63" else 0   # developer A/B
     for c in ctxs:                                 # -0.4 has the most triangles: sizes the vertex buffers
-        c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING | t63)
+        c.graph_build(eq, step, iso=-0.4, flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_TIMING | mc_amd.FLAG_NO_INTERP | t63)
 
     def play(frame_isos, depth=depth):
         """Frame k goes to context k % depth (its own buffers and stream), so `depth` frames are in flight; EVERY frame's
@@ -230,7 +230,7 @@ def isosweep(args, torch, mc_amd, world, rank, local_rank, dist):
     # see the gaps between a graph's nodes (for kernels under 100 us those gaps were 10-55 % of the figure)
     kt = np.zeros(4)
     for iso in isos:
-        r = ctx.march(eq, step, float(iso), flags=mc_amd.FLAG_NORMALS | t63)
+        r = ctx.march(eq, step, float(iso), flags=mc_amd.FLAG_NORMALS | mc_amd.FLAG_NO_INTERP | t63)
         kt += (r.ms_classify, r.ms_scan, r.ms_emit, r.ms_total)
     kt /= frames
     n1 = mc_amd.cells_per_axis(step)
@@ -342,6 +342,7 @@ def main():
     if args.slab_of > 1 and world == 1:
         zb, ze = mc_amd.shard_layers(n1, args.slab_of, args.slab_of // 2)
     flags = 0 if args.no_normals else mc_amd.FLAG_NORMALS
+    flags |= mc_amd.FLAG_NO_INTERP   # steady state: every sweep here runs the kernels specialised for the equation (the cold start has its own section)
     if os.environ.get("MC_FORCE63") == "63":     # developer A/B: 63-row classify tiles whatever the grid size
         flags |= mc_amd.FLAG_TILE63
     ctx = mc_amd.Context(local_rank)
@@ -510,6 +511,7 @@ def main():
 
     # the same K steps with ONE sweep in flight (context 0 alone, each sweep behind the previous one), for comparison
     serial_ms = None
+    kt1 = None
     ctx1 = None
     if not multi and not args.no_graph and depth > 1:
         ctx1 = mc_amd.Context(local_rank)   # (its own buffers and capture, without FLAG_BATCH)
@@ -525,6 +527,14 @@ def main():
         ctx1.graph_wait()
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        # ... and that caller's kernels, each alone: where the library launches a single sweep differently from a batch
+        # (MC_FLAG_BATCH: on small grids the emit kernel of an expensive f), these are the single sweep's -- the ones a
+        # rocprofv3 kernel trace of `bench.py --in-flight 1` shows (profiles/*_kernel_stats_<workload>.csv)
+        kt1 = np.zeros(4)
+        for _ in range(args.steps):
+            r1 = ctx1.march(eq, step, 0.0, scale, flags=lat_flags, z_begin=zb, z_end=ze)
+            kt1 += (r1.ms_classify, r1.ms_scan, r1.ms_emit, r1.ms_total)
+        kt1 /= max(args.steps, 1)
         ctx1.close()
 
     # per-kernel GPU times for the roofline: the same K sweeps again, one at a time and kernel by kernel (mc_march), each
@@ -622,6 +632,9 @@ def main():
                   "algorithmic_bytes_per_launch": int(72.0 * t_launch), "avg_launch_ms": round(ms_emit, 4)}
         out["roofline"], out["second_roofline"] = (r_emit, r_cls) if ms_emit > ms_cls else (r_cls, r_emit)
         if serial_ms is not None:   # ONE sweep in flight: what a single march() / recalculate() call costs (steady state)
+            out["kernel_ms_one_in_flight"] = {"classify": round(float(kt1[0]), 4), "scan": round(float(kt1[1]), 4), "emit": round(float(kt1[2]), 4),
+                                              "gpu_total": round(float(kt1[3]), 4),
+                                              "note": "the kernels of a caller that issues one sweep at a time (no MC_FLAG_BATCH); `kernel_ms` are the batch's"}
             out["ms_per_step_one_in_flight"] = round(serial_ms, 4)
             out["mvoxels_per_s_one_in_flight"] = round(cells / (serial_ms * 1e-3) / 1e6, 2)
             out["mtris_per_s_one_in_flight"] = round(tris / (serial_ms * 1e-3) / 1e6, 3)

@@ -22,7 +22,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r03"
+tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r04"
 wl = (sys.argv[sys.argv.index("--workloads") + 1] if "--workloads" in sys.argv else "sphere1024,torus512,gyroid1024,goursat512").split(",")
 out = os.path.join(ROOT, "gpurun_out", "profile")
 prof = os.path.join(ROOT, "profiles")
