@@ -308,9 +308,11 @@ typedef struct mc_shard {
  * measured cost passes its own).  Slab i runs on ctxs[i] -- all slabs at once, one host thread each -- and leaves results[i]
  * exactly as mc_march would; shards[i] (optional) receives its offsets.  With MC_FLAG_INDEXED every slab is welded as a part
  * of the whole grid (MC_FLAG_SEAM is implied) and re-based, so the slabs' vertex_list / tri_list / normals concatenated in
- * slab order are the single sweep's Poly_Data bit for bit.  Constraints are per context: set them on every context
- * (mc_set_constraint).  Seed mode (whole grid only) is refused.  On an error the first failing slab's code and text are
- * reported. */
+ * slab order are the single sweep's Poly_Data bit for bit.  Constraints and seed settings are per context: set them on
+ * every context (mc_set_constraint, mc_set_seed, mc_seed_mode).  Seed mode follows one connected component through the
+ * whole grid (marching.cpp:310-331), which needs every layer on one device: with seed mode on (on ctxs[0]) the whole range
+ * is swept by ctxs[0] and the other contexts get EMPTY slabs -- same results layout, same mesh as mc_march.  On an error
+ * the first failing slab's code and text are reported. */
 int mc_march_sharded(mc_context *const *ctxs, int n, const mc_params *p, const int32_t *bounds, mc_result *results,
                      mc_shard *shards);
 /* The slabs' results of the last mc_march_sharded on these contexts, concatenated in slab order into host memory: what

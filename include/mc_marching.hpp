@@ -349,8 +349,8 @@ public:
     // Z slab per entry and sweeps them at once, one context per entry (a device may be listed more than once).  The mesh
     // get_poly_data() returns is the single sweep's -- the sweep is z-major (marching.cpp:375), so the slabs' lists
     // concatenate to it, and the indexed mesh is welded across the seams (mc_hip.h: mc_march_sharded).  An empty list
-    // returns to the one context the object was constructed on.  Seed mode needs the whole grid on one device and makes
-    // recalculate() fail while a list of two or more devices is set.  false: a device of the list cannot be used.
+    // returns to the one context the object was constructed on.  Seed mode needs the whole grid on one device: while it is
+    // on, the first device of the list sweeps everything (the mesh is the same).  false: a device of the list cannot be used.
     bool set_devices(const std::vector<int>& devices) {
         std::vector<std::unique_ptr<Context>> made;
         try {

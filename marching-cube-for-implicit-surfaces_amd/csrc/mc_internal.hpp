@@ -9,6 +9,8 @@ int mc_internal_fail(int code, const char* fmt, ...) __attribute__((format(print
 const mc_result* mc_internal_last(const mc_context* ctx);
 // the HIP device the context lives on
 int mc_internal_device(const mc_context* ctx);
+// Marching::seed_mode is on for this context (mc_seed_mode)
+bool mc_internal_seed_on(const mc_context* ctx);
 
 // A host thread with a LARGE stack (64 MB).  The library's own threads run hiprtc (LLVM: deep recursion on the kernels'
 // large functions) or whole sweeps that may; a default thread stack is as small as 2 MB when the process runs with an

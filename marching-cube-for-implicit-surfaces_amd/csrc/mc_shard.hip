@@ -158,6 +158,15 @@ int mc_march_sharded(mc_context* const* ctxs, int n, const mc_params* p, const i
     std::vector<int> b;
     int r = slab_bounds(bounds, n, zb, ze, b);
     if (r) return r;
+    // Seed mode (marching.cpp:310-331) follows ONE connected component through the whole grid: the component labelling needs
+    // every layer on one device.  With seed mode on (on the first context: the facade keeps all of a Marching object's
+    // contexts in the same state) the whole range is therefore swept by the first context and the others get empty slabs --
+    // the same results layout, the same mesh as mc_march, no error for a caller that has a device list set.
+    if (mc_internal_seed_on(ctxs[0])) {
+        if (zb != 0 || ze != n1) return mc_internal_fail(MC_ERR_ARG, "seed mode needs the whole grid in one sweep (z_begin 0, z_end -1)");
+        b[0] = zb;
+        for (int i = 1; i <= n; ++i) b[(size_t)i] = ze;
+    }
     const bool indexed = (p->flags & MC_FLAG_INDEXED) != 0;
     const uint32_t flags = indexed ? (p->flags | MC_FLAG_SEAM) : p->flags;
     std::vector<int> rc((size_t)n, MC_OK);

@@ -117,15 +117,23 @@ int main(int argc, char** argv) {
             if (!(ok_i && ok_s && ok_o)) ++bad;
             if (wi.t.empty() && std::strcmp(c.eq, "z") != 0) ++bad;  // (a case that compares nothing proves nothing)
         }
-        // seed mode keeps the whole grid on one device: a device list of two refuses it, a list of one runs it
-        Marching seeded;
-        seeded.set_evaluator(&ev);
-        seeded.set_grid_step_size(c.step);
-        seeded.seed_mode(true);
-        seeded.set_devices({base.empty() ? 0 : base[0], base.empty() ? 0 : base[0]});
-        if (seeded.recalculate()) {
-            std::printf("seed mode over two slabs was not refused\n");
-            ++bad;
+        // seed mode follows one component through the whole grid: with a device list set the first device sweeps everything,
+        // and the mesh is the one a Marching object without a list gets
+        if (!*c.cons && c.sx == 1.0f) {
+            Mesh s1, s2;
+            Marching seeded, seeded_list;
+            for (Marching* m : {&seeded, &seeded_list}) {
+                m->set_evaluator(&ev);
+                m->set_grid_step_size(c.step);
+                m->set_surface_constant(c.iso);
+                m->seed_mode(true);
+                m->set_seed(0.0f, 0.0f, 1.0f);
+            }
+            seeded_list.set_devices({base.empty() ? 0 : base[0], base.empty() ? 0 : base[0], base.empty() ? 0 : base[0]});
+            if (!sweep(seeded, true, s1) || !sweep(seeded_list, true, s2)) return 7;
+            const bool ok = same_bits(s1.v, s2.v) && s1.t == s2.t && same_bits(s1.n, s2.n);
+            std::printf("%s seed mode with a device list: tris=%zu %s\n", c.eq, s2.t.size() / 3, ok ? "same" : "DIFFERENT");
+            if (!ok) ++bad;
         }
     }
     if (bad) {

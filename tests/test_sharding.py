@@ -264,8 +264,9 @@ def test_sharded_entry_points_refuse_bad_arguments_without_a_gpu(mc):
 @pytest.mark.gpu
 def test_reference_style_caller_with_a_device_list(mc):
     """Marching::set_devices({0, 0, ...}) -- 2, 3, 4 and 8 slabs on the one GPU -- hands out the single sweep's Poly_Data and
-    soup bit for bit (five surfaces, one with a constraint and anisotropic scale, one lying in the lattice planes); seed
-    mode over two slabs is refused.  All in C++ through the facade and the C ABI."""
+    soup bit for bit (five surfaces, one with a constraint and anisotropic scale, one lying in the lattice planes); with seed
+    mode on, the list's first device sweeps the whole grid and the mesh is the single-device one.  All in C++ through the
+    facade and the C ABI."""
     r = subprocess.run([str(build_sharded_caller(mc))], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
