@@ -203,6 +203,8 @@ int mc_march_simple(mc_context *ctx, const char *equation, int grid_res, float i
  * mc_copy_codes:    n_cells bytes, compact, sweep order x-fastest. */
 int mc_copy_vertices(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_soup(mc_context *ctx, float *host, uint64_t max_tris);
+/* the other half of mc_copy_vertices: n_tris*9 floats, the unit normals (MC_FLAG_NORMALS) in the same order */
+int mc_copy_soup_normals(mc_context *ctx, float *host, uint64_t max_tris);
 int mc_copy_codes(mc_context *ctx, uint8_t *host, uint64_t max_bytes);
 /* mc_copy_indexed: the indexed mesh of the last MC_FLAG_INDEXED sweep: vertex_list (n_verts*3 floats), tri_list
  * (n_tris*3 uint32) and the area-weighted vertex normals (n_verts*3 floats); any of the three may be NULL.

@@ -370,6 +370,7 @@ public:
     void set_indexed(bool b) { indexed_ = b; }
 
     void reset_all_data() {  // marching.cpp:293-305
+        iota_upto_ = 0;
         poly_data_.vertex_list.clear();
         poly_data_.tri_list.clear();
         poly_data_.normal_list.clear();
@@ -381,8 +382,33 @@ public:
 
     // marching.cpp:308, full-sweep branch :368-384.  false = no evaluator or a GPU/compile error.
     bool recalculate() {
-        reset_all_data();
+        // marching.cpp:293-305 reset_all_data: the mesh is gone until the sweep has delivered.  The big vectors are NOT
+        // cleared up front -- clear() + resize() would value-initialise (memset) every element again, 180 MB per sweep at
+        // grid_res 1024, tens of milliseconds of host time around a 1.6 ms GPU job; they are resized in place (free when the
+        // counts repeat, as in an animation) and emptied only if the sweep fails.
+        struct OnFailure {
+            Poly_Data& pd;
+            bool ok = false;
+            ~OnFailure() {
+                if (!ok) {
+                    pd.vertex_list.clear();
+                    pd.tri_list.clear();
+                    pd.normal_list.clear();
+                }
+            }
+        } guard{poly_data_};
+        poly_data_.step_data.intersect_coord.clear();  // marching.cpp:296-298
+        poly_data_.step_data.tri_vlist.clear();
+        poly_data_.step_data.edge_list.clear();
+        poly_data_.step_data.step_i = -2;              // reset_step, marching.cpp:288-290
         error_.clear();
+        const bool done = recalculate_impl();
+        guard.ok = done;
+        return done;
+    }
+
+private:
+    bool recalculate_impl() {
         if (!evaluator_) return false;
         if (!push_state()) {
             error_ = mc_last_error();
@@ -409,7 +435,8 @@ public:
         if (indexed) {
             poly_data_.vertex_list.resize((size_t)r.n_verts * 3);
             poly_data_.tri_list.resize((size_t)r.n_tris * 3);
-            if (normals_) poly_data_.normal_list.resize((size_t)r.n_verts * 3);
+            poly_data_.normal_list.resize(normals_ ? (size_t)r.n_verts * 3 : 0);
+            iota_upto_ = 0;
             static_assert(sizeof(unsigned int) == sizeof(uint32_t), "tri_list is handed to the GPU library as uint32");
             if (mc_copy_indexed(ctx_.get(), poly_data_.vertex_list.data(), reinterpret_cast<uint32_t*>(poly_data_.tri_list.data()),
                                 normals_ ? poly_data_.normal_list.data() : nullptr, r.n_verts, r.n_tris) != MC_OK) {
@@ -418,26 +445,29 @@ public:
             }
             return true;
         }
+        // soup: positions and normals are split on the GPU and land in Poly_Data's vectors directly (no staging vector, no
+        // host loop over 30 M vertices); tri_list = 0 .. 3T-1
         const size_t nv = (size_t)r.n_tris * 3;
-        std::vector<float> inter(nv * 6);
-        if (nv && mc_copy_vertices(ctx_.get(), inter.data(), r.n_tris) != MC_OK) {
+        poly_data_.vertex_list.resize(nv * 3);
+        poly_data_.normal_list.resize(nv * 3);
+        if (nv && (mc_copy_soup(ctx_.get(), poly_data_.vertex_list.data(), r.n_tris) != MC_OK ||
+                   mc_copy_soup_normals(ctx_.get(), poly_data_.normal_list.data(), r.n_tris) != MC_OK)) {
             error_ = mc_last_error();
             return false;
         }
-        poly_data_.vertex_list.resize(nv * 3);
-        poly_data_.normal_list.resize(nv * 3);
-        poly_data_.tri_list.resize(nv);
-        for (size_t i = 0; i < nv; ++i) {
-            for (int k = 0; k < 3; ++k) {
-                poly_data_.vertex_list[3 * i + k] = inter[6 * i + k];
-                poly_data_.normal_list[3 * i + k] = inter[6 * i + 3 + k];
-            }
-            poly_data_.tri_list[i] = (unsigned int)i;
-        }
+        fill_iota(nv);
         return true;
     }
+    // tri_list = 0, 1, 2, ... (soup); written only where it is not that already
+    void fill_iota(size_t nv) {
+        std::vector<unsigned int>& t = poly_data_.tri_list;
+        const bool was_iota = iota_upto_ > 0 && t.size() >= 1 && t.size() <= iota_upto_;
+        const size_t keep = was_iota ? (t.size() < nv ? t.size() : nv) : 0;
+        t.resize(nv);
+        for (size_t i = keep; i < nv; ++i) t[i] = (unsigned int)i;
+        iota_upto_ = nv;
+    }
 
-private:
     // recalculate() over the device list: one slab per context, all at once; the hand-over is the single sweep's
     bool recalculate_sharded(const mc_params& p, bool indexed) {
         const int n = (int)shard_ctx_.size();
@@ -472,7 +502,8 @@ private:
         if (indexed) {
             poly_data_.vertex_list.resize((size_t)nv * 3);
             poly_data_.tri_list.resize((size_t)nt * 3);
-            if (normals_) poly_data_.normal_list.resize((size_t)nv * 3);
+            poly_data_.normal_list.resize(normals_ ? (size_t)nv * 3 : 0);
+            iota_upto_ = 0;
             if (mc_copy_sharded_indexed(cs.data(), n, poly_data_.vertex_list.data(), reinterpret_cast<uint32_t*>(poly_data_.tri_list.data()),
                                         normals_ ? poly_data_.normal_list.data() : nullptr, nv, nt) != MC_OK) {
                 error_ = mc_last_error();
@@ -481,21 +512,17 @@ private:
             return true;
         }
         const size_t nvert = (size_t)nt * 3;
-        std::vector<float> inter(nvert * 6);
-        if (nvert && mc_copy_sharded_vertices(cs.data(), n, inter.data(), nt) != MC_OK) {
-            error_ = mc_last_error();
-            return false;
-        }
         poly_data_.vertex_list.resize(nvert * 3);
         poly_data_.normal_list.resize(nvert * 3);
-        poly_data_.tri_list.resize(nvert);
-        for (size_t i = 0; i < nvert; ++i) {
-            for (int k = 0; k < 3; ++k) {
-                poly_data_.vertex_list[3 * i + k] = inter[6 * i + k];
-                poly_data_.normal_list[3 * i + k] = inter[6 * i + 3 + k];
+        for (int i = 0; i < n; ++i) {  // every slab's halves straight to their place in the whole list
+            const size_t at = (size_t)shards_[(size_t)i].tri_offset * 9;
+            if (rs[(size_t)i].n_tris && (mc_copy_soup(cs[(size_t)i], poly_data_.vertex_list.data() + at, rs[(size_t)i].n_tris) != MC_OK ||
+                                         mc_copy_soup_normals(cs[(size_t)i], poly_data_.normal_list.data() + at, rs[(size_t)i].n_tris) != MC_OK)) {
+                error_ = mc_last_error();
+                return false;
             }
-            poly_data_.tri_list[i] = (unsigned int)i;
         }
+        fill_iota(nvert);
         return true;
     }
 
@@ -577,6 +604,7 @@ public:
         }
         poly_data_.vertex_list.insert(poly_data_.vertex_list.end(), pts.begin(), pts.end());
         poly_data_.tri_list.insert(poly_data_.tri_list.end(), tri.begin(), tri.end());
+        iota_upto_ = 0;
         return true;
     }
     const mc_result& last_result() const { return last_; }
@@ -590,6 +618,7 @@ private:
         float rhs = 0.0f;
     } cons_[3];
 
+    size_t iota_upto_ = 0;  // tri_list[0 .. iota_upto_) is known to be 0, 1, 2, ... (the soup hand-over wrote it; 0: unknown)
     Context& ctx_;
     std::vector<std::unique_ptr<Context>> shard_ctx_;  // set_devices: one context per listed device (empty: ctx_ alone)
     std::vector<mc_shard> shards_;

@@ -31,7 +31,7 @@ COMM_ID_BYTES = 128
 ABI_SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_device_count", "mc_expr_check", "mc_expr_validate", "mc_expr_dump",
     "mc_expr_debug_eval_host", "mc_context_create", "mc_context_destroy", "mc_eval_points", "mc_march",
-    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
+    "mc_march_simple", "mc_jit_precompile", "mc_copy_vertices", "mc_copy_soup", "mc_copy_soup_normals", "mc_copy_codes", "mc_copy_indexed", "mc_cells_per_axis", "mc_graph_build",
     "mc_graph_replay", "mc_graph_replay_async", "mc_graph_wait", "mc_stream", "mc_set_constraint", "mc_use_constraint", "mc_set_extensions",
     "mc_set_seed", "mc_seed_mode", "mc_context_set_extensions", "mc_index_rebase",
     "mc_shard_layers", "mc_march_sharded", "mc_copy_sharded_vertices", "mc_copy_sharded_indexed", "mc_copy_sharded_codes",
@@ -102,6 +102,7 @@ def lib():
         L.mc_march_simple.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_uint32, C.POINTER(McResult)]
         L.mc_copy_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_soup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_copy_soup_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_copy_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         L.mc_graph_replay_async.argtypes = [C.c_void_p, C.c_float]
@@ -215,6 +216,13 @@ class Result:
         a = np.empty((self.n_tris, 3, 3), dtype=np.float32)
         if self.n_tris:
             _check(lib().mc_copy_soup(self._ctx._h, a.ctypes.data, self.n_tris))
+        return a
+
+    def soup_normals(self) -> np.ndarray:
+        """(n_tris, 3, 3) float32: the unit normals of soup()'s vertices."""
+        a = np.empty((self.n_tris, 3, 3), dtype=np.float32)
+        if self.n_tris:
+            _check(lib().mc_copy_soup_normals(self._ctx._h, a.ctypes.data, self.n_tris))
         return a
 
     def indexed(self):

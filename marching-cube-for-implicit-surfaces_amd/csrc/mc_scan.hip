@@ -262,13 +262,13 @@ extern "C" __global__ __launch_bounds__(256) void mc_index_add(u32* __restrict__
     if (i < n) tlist[i] += delta;
 }
 
-// positions only: verts[T*3][6] -> soup[T*3][3]
-extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __restrict__ verts, float* __restrict__ soup, u64 nverts) {
+// one half of every vertex: verts[T*3][6] -> soup[T*3][3]; half = 0: positions, 3: normals
+extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __restrict__ verts, float* __restrict__ soup, u64 nverts, u32 half) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
     if (i < nverts) {
-        soup[3 * i + 0] = verts[6 * i + 0];
-        soup[3 * i + 1] = verts[6 * i + 1];
-        soup[3 * i + 2] = verts[6 * i + 2];
+        soup[3 * i + 0] = verts[6 * i + half + 0];
+        soup[3 * i + 1] = verts[6 * i + half + 1];
+        soup[3 * i + 2] = verts[6 * i + half + 2];
     }
 }
 

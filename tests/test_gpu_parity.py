@@ -44,6 +44,7 @@ def check_against_oracle(mc, orc, ctx, eq, step, iso=0.0, scale=(1.0, 1.0, 1.0),
     v = r.vertices()
     assert_same_floats(v[:, :, :3], o.soup, "positions")
     assert_same_floats(r.soup(), o.soup, "soup copy")
+    assert np.array_equal(u32(r.soup_normals()), u32(v[:, :, 3:])), "mc_copy_soup_normals is not the normal half of mc_copy_vertices"
     if flags & mc.FLAG_NORMALS:
         d = np.abs(v[:, :, 3:] - o.normals)
         assert not d.size or np.nanmax(d) <= TOL_NRM, f"normals differ by {np.nanmax(d)}"
