@@ -2623,7 +2623,8 @@ __device__ __forceinline__ u32 mc_find_record(const McParams& p, const u32* __re
     u32 lo = cb.y, n = cb.x >> 16;
     const u32 want = (u32)(qx & 255);
     if (n <= 4u) {
-        const u32 rb = recs[lo + 1u], rc_ = recs[lo + 2u], rd = recs[lo + 3u];  // (the buffer has slack behind its last record)
+        u32 rb = recs[lo + 1u], rc_ = recs[lo + 2u], rd = recs[lo + 3u];  // (the buffer has slack behind its last record)
+        asm volatile("" : "+v"(rb), "+v"(rc_), "+v"(rd));  // the three loads travel together (see mc_vn_cell: MC_TOGETHER)
         return (n > 3u && (rd & 0xFFu) <= want) ? lo + 3u : (n > 2u && (rc_ & 0xFFu) <= want) ? lo + 2u : (n > 1u && (rb & 0xFFu) <= want) ? lo + 1u : lo;
     }
     while (n > 1u) {  // lower bound
@@ -2676,8 +2677,10 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                 }
                 if (!(qx == ix && qy == iy && qz == iz)) {
                     const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
-                    o = recown[q] & 0xFFFu;
-                    vb = recvb[q];
+                    u32 oq = recown[q], vq = recvb[q];
+                    asm volatile("" : "+v"(oq), "+v"(vq));  // (one level)
+                    o = oq & 0xFFFu;
+                    vb = vq;
                 }
                 eidx[e] = vb + (u32)__builtin_popcount(o & ((1u << qe) - 1u));
             }
@@ -2737,23 +2740,36 @@ __device__ __forceinline__ u32 mc_find_record_opt(const McParams& p, const u32* 
 // take a second pass, one lane per vertex.
 #define MC_VN_CAP 256  // vertices of one kind (edge key / corner key) listed at a time; 16 records own at most 192
 // what cell (qx, qy, qz) adds to vertex v: its triangles in table order; out[t] = {cross(B-A, C-A), corners that are v}
+// The triangles of cell (qx, qy, qz) that have vertex v at a corner -> out[t] = {face normal, number of such corners}.
+// match_edge >= 0: v's key is a lattice EDGE, which is edge `match_edge` of this cell -- the cell's table row says which of its
+// triangles touch it, nothing is read from tri_list; match_edge < 0 (v is welded to a lattice corner, several edges lead to
+// it): the triangles' corner indices are compared with v.  The face normals come from mc_tnormal (mc_scan.hip).
 __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb,
-                                           const u32* __restrict__ segtri, const u32* __restrict__ tlist, const float* __restrict__ vlist,
-                                           u64 nverts, int qx, int qy, int qz, u32 v, float4* out) {
+                                           const u32* __restrict__ segtri, const u32* __restrict__ tlist, const float4* __restrict__ tnrm,
+                                           const u64* s_trirow, u64 cap_tris, int qx, int qy, int qz, u32 v, int match_edge, float4* out) {
 #pragma unroll
     for (int t = 0; t < 5; ++t) out[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // the cell's record: segment -> its records (ascending in x).  Four dependent loads fewer than a search that ends in the
     // record index: the segment's first triangle comes with its counts, up to four records are fetched at once and the one
     // wanted is picked (a segment of the sphere holds 1-3), longer segments are searched
+    // The loads of one level must TRAVEL TOGETHER: left to itself the compiler sinks each load to its first use behind the
+    // branches in between (it saves a load on the paths that leave early) and the chain becomes one memory round trip per
+    // LOAD instead of one per LEVEL -- the four records of a segment were fetched one after the other, each behind a wait,
+    // the five face normals likewise (round 4, seen in the ISA).  MC_TOGETHER pins the values of a level at one point: the
+    // loads are issued back to back, one wait covers them.
+#define MC_TOGETHER2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define MC_TOGETHER4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
     if (qx < 0 || qy < 0 || qx >= p.n1 || qy >= p.n1 || qz < p.z_begin || qz >= p.z_begin + p.nz) return;
     const u32 seg = (u32)(((qz - p.z_begin) * p.n1 + qy) * p.nchunk + (qx >> 8));
-    const uint2 cb = segcb[seg];
-    const u32 st = segtri[seg];
+    uint2 cb = segcb[seg];
+    u32 st = segtri[seg];
+    MC_TOGETHER2(cb.y, st);
     const u32 n = cb.x >> 16, want = (u32)(qx & 255);
     if (n == 0u) return;
     u32 rec;
     if (n <= 4u) {
-        const u32 ra = recs[cb.y], rb = recs[cb.y + 1u], rc_ = recs[cb.y + 2u], rd = recs[cb.y + 3u];  // (the buffer has slack behind its last record)
+        u32 ra = recs[cb.y], rb = recs[cb.y + 1u], rc_ = recs[cb.y + 2u], rd = recs[cb.y + 3u];  // (the buffer has slack behind its last record)
+        MC_TOGETHER4(ra, rb, rc_, rd);
         rec = (ra & 0xFFu) == want ? ra : (n > 1u && (rb & 0xFFu) == want) ? rb : (n > 2u && (rc_ & 0xFFu) == want) ? rc_ : (n > 3u && (rd & 0xFFu) == want) ? rd : 0xFFFFFFFFu;
         if (rec == 0xFFFFFFFFu) return;
     } else {
@@ -2772,27 +2788,51 @@ __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restr
     }
     const u32 nt = (rec >> 17) & 7u;
     const u32 t0 = st + (rec >> 20);
-    u32 i1[5], i2[5], i3[5];
+    u32 hits[5];
+    if (match_edge >= 0) {
+        const u32 code = (rec >> 8) & 0xFFu;
+        const u64 tr = s_trirow[((rec >> 16) & 1u) ? 255u - code : code];  // marching.cpp:542-547
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {  // (all index loads first, then all position loads: the loads of one level travel together)
-        i1[t] = i2[t] = i3[t] = 0xFFFFFFFFu;
-        if ((u32)t < nt) {
-            const u32* tri = tlist + 3ull * (t0 + (u32)t);
-            i1[t] = tri[0];
-            i2[t] = tri[1];
-            i3[t] = tri[2];
+        for (int t = 0; t < 5; ++t) {
+            const u32 trip = (u32)(tr >> (12 * t)) & 0xFFFu, e = (u32)match_edge;
+            hits[t] = (u32)t < nt ? ((trip & 15u) == e ? 1u : 0u) + (((trip >> 4) & 15u) == e ? 1u : 0u) + ((trip >> 8) == e ? 1u : 0u) : 0u;
+        }
+    } else {
+        // (every triangle's three indices, wanted or not -- triangle 0 of the list stands in for the ones that are not, its
+        // line is in every lane's cache --, so that the fifteen loads are one level)
+        u32 ia[5], ib[5], ic[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const bool wanted = (u32)t < nt && (u64)(t0 + (u32)t) < cap_tris;
+            const u32* tri = tlist + 3ull * (wanted ? t0 + (u32)t : 0u);
+            ia[t] = tri[0];
+            ib[t] = tri[1];
+            ic[t] = tri[2];
+        }
+        MC_TOGETHER4(ia[0], ib[0], ic[0], ia[1]);
+        MC_TOGETHER4(ib[1], ic[1], ia[2], ib[2]);
+        MC_TOGETHER4(ic[2], ia[3], ib[3], ic[3]);
+        MC_TOGETHER4(ia[4], ib[4], ic[4], ia[0]);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const bool wanted = (u32)t < nt && (u64)(t0 + (u32)t) < cap_tris;
+            hits[t] = wanted ? (ia[t] == v ? 1u : 0u) + (ib[t] == v ? 1u : 0u) + (ic[t] == v ? 1u : 0u) : 0u;
         }
     }
+    // the face normals of the triangles that touch the vertex (the others read triangle 0's, and drop it): one level
+    float4 fn[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
-        const int hits = (i1[t] == v ? 1 : 0) + (i2[t] == v ? 1 : 0) + (i3[t] == v ? 1 : 0);
-        if ((u32)t >= nt || !hits || i1[t] >= nverts || i2[t] >= nverts || i3[t] >= nverts) continue;
-        const float ax_ = vlist[3ull * i1[t]], ay_ = vlist[3ull * i1[t] + 1], az_ = vlist[3ull * i1[t] + 2];
-        const float bax = vlist[3ull * i2[t]] - ax_, bay = vlist[3ull * i2[t] + 1] - ay_, baz = vlist[3ull * i2[t] + 2] - az_;
-        const float cax = vlist[3ull * i3[t]] - ax_, cay = vlist[3ull * i3[t] + 1] - ay_, caz = vlist[3ull * i3[t] + 2] - az_;
-        // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
-        out[t] = make_float4(bay * caz - cay * baz, baz * cax - caz * bax, bax * cay - cax * bay, __builtin_bit_cast(float, (u32)hits));
+        if ((u64)(t0 + (u32)t) >= cap_tris) hits[t] = 0u;
+        fn[t] = tnrm[hits[t] ? t0 + (u32)t : 0u];
     }
+    MC_TOGETHER4(fn[0].x, fn[1].x, fn[2].x, fn[3].x);
+    MC_TOGETHER4(fn[4].x, fn[0].w, fn[1].w, fn[2].w);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        if (hits[t] && fn[t].w != 0.0f) out[t] = make_float4(fn[t].x, fn[t].y, fn[t].z, __builtin_bit_cast(float, hits[t]));
+#undef MC_TOGETHER2
+#undef MC_TOGETHER4
 }
 // vNormal[i] = normal + vNormal[i], once per corner that is the vertex (normal.h:22-31): almost always 0 or 1 times -- the
 // second and third block are skipped by the whole wave unless a degenerate triangle has the vertex at two corners
@@ -2818,8 +2858,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                                                                         const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                         const u32* __restrict__ recown, const u32* __restrict__ recvb,
                                                                         const u32* __restrict__ segtri, const u32* __restrict__ tlist,
-                                                                        const float* __restrict__ vlist, float* __restrict__ vnrm, u64 nverts) {
+                                                                        const float4* __restrict__ tnrm, float* __restrict__ vnrm, u64 nverts,
+                                                                        u64 cap_tris) {
     // (LDS is what limits the waves per CU here, and the kernel lives on them: 71 % of its wave-cycles are waits for loads)
+    __shared__ u64 s_trirow[256];  // the case table's rows (marching_lookup.h:64-320, nibble-packed): which triangles of a cell touch an edge
+    for (int i = (int)threadIdx.x; i < 256; i += 64 * MC_WPB_I) s_trirow[i] = c_tri_row[i];  // (in front of the macro's barrier)
     __shared__ unsigned short s_item[MC_WPB_I][2 * MC_VN_CAP];  // the listed vertices: record lane | edge << 6; edge keys from the front, corner keys from the back
     __shared__ uint2 s_rc[MC_WPB_I][64];                         // per record of the chunk: {ix | iy << 16, iz}
     __shared__ uint2 s_rv[MC_WPB_I][64];                         // ... {first vertex, owned edges}
@@ -2886,9 +2929,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                     int b[3] = {(int)(c.x & 0xFFFFu) + (int)((MC_EDGE_OX >> e) & 1u), (int)(c.x >> 16) + (int)((MC_EDGE_OY >> e) & 1u),
                                 (int)c.y + (int)((MC_EDGE_OZ >> e) & 1u)};
                     const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
-                    b[a1] -= 1 - (int)(j >> 1);
-                    b[a0] -= 1 - (int)(j & 1u);
-                    mc_vn_cell(p, recs, segcb, segtri, tlist, vlist, nverts, b[0], b[1], b[2], v, mine);
+                    const int d1 = 1 - (int)(j >> 1), d0 = 1 - (int)(j & 1u);
+                    b[a1] -= d1;
+                    b[a0] -= d0;
+                    // (in that cell the vertex's lattice edge is edge mc_edge_of(ax, d0, d1): mc_resolve's rule)
+                    mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_trirow, cap_tris, b[0], b[1], b[2], v, mc_edge_of(ax, d0, d1), mine);
                 }
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 #pragma unroll
@@ -2933,7 +2978,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                     for (int dy = -1; dy <= (ax == 1 ? 1 : 0); ++dy)
                         for (int dx = -1; dx <= (ax == 0 ? 1 : 0); ++dx) {
                             float4 cc[5];
-                            mc_vn_cell(p, recs, segcb, segtri, tlist, vlist, nverts, bx + dx, by + dy, bz + dz, v, cc);
+                            mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_trirow, cap_tris, bx + dx, by + dy, bz + dz, v, -1, cc);
 #pragma unroll
                             for (int t = 0; t < 5; ++t) mc_vn_add(cc[t], sx, sy, sz);
                         }

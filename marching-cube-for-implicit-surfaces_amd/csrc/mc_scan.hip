@@ -262,6 +262,30 @@ extern "C" __global__ __launch_bounds__(256) void mc_index_add(u32* __restrict__
     if (i < n) tlist[i] += delta;
 }
 
+// CalculateNormal (Source/normal.h:3-41), first half: the face normal of every triangle of the welded mesh, ONCE --
+// glm::cross(B - A, C - A) from the welded positions, the reference's operation order (normal.h:17-20; this file is built
+// with -ffp-contract=off like every other) -- so that mc_vnormal, which sums them per vertex in the reference's order, reads
+// 16 bytes per triangle it visits instead of nine scattered floats (each triangle is visited ~3 times: round 4, 0.645 ->
+// see DESIGN.md section 4 "Indexed mesh").  .w = 1: the triangle counts; 0: one of its corners lies outside the vertex list
+// (a vertex owned by the layer below a ghost layer, or beyond a captured graph's capacity) -- such a triangle is skipped by
+// the sum, as before.  total: the sweep's triangle count on the device (the scan's last offset).
+extern "C" __global__ __launch_bounds__(256) void mc_tnormal(const u32* __restrict__ tlist, const float* __restrict__ vlist, float4* __restrict__ tnrm,
+                                                   const uint2* __restrict__ total, u64 cap_tris, u64 nverts) {
+    const u64 tri = (u64)blockIdx.x * 256ull + threadIdx.x;
+    const u64 nt = (u64)total->x < cap_tris ? (u64)total->x : cap_tris;
+    if (tri >= nt) return;
+    const u32 i1 = tlist[3ull * tri], i2 = tlist[3ull * tri + 1], i3 = tlist[3ull * tri + 2];
+    if (i1 >= nverts || i2 >= nverts || i3 >= nverts) {
+        tnrm[tri] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const float ax_ = vlist[3ull * i1], ay_ = vlist[3ull * i1 + 1], az_ = vlist[3ull * i1 + 2];
+    const float bax = vlist[3ull * i2] - ax_, bay = vlist[3ull * i2 + 1] - ay_, baz = vlist[3ull * i2 + 2] - az_;
+    const float cax = vlist[3ull * i3] - ax_, cay = vlist[3ull * i3 + 1] - ay_, caz = vlist[3ull * i3 + 2] - az_;
+    // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
+    tnrm[tri] = make_float4(bay * caz - cay * baz, baz * cax - caz * bax, bax * cay - cax * bay, 1.0f);
+}
+
 // one half of every vertex: verts[T*3][6] -> soup[T*3][3]; half = 0: positions, 3: normals
 extern "C" __global__ __launch_bounds__(256) void mc_pack_soup(const float* __restrict__ verts, float* __restrict__ soup, u64 nverts, u32 half) {
     const u64 i = (u64)blockIdx.x * 256ull + threadIdx.x;
