@@ -133,13 +133,23 @@ __device__ __forceinline__ float mc_pow_int_rt(float a, int n) {  // mc_pow_int<
     if (n < 0) r = 1.0 / r;
     return (float)r;
 }
+// The register file lives in LDS, one column per thread of the workgroup (the largest workgroup of this file has 512
+// threads: mc_emit_direct): a register number is uniform, so an access is one conflict-free ds_read / ds_write at
+// [register][thread].  (In private memory -- a dynamically indexed array goes to scratch -- every operand was a trip to
+// memory: the interpreter build swept 1025^3 cells in 45 ms; the values are only live inside one call of mc_f.)  The
+// interpreter build's workgroups have at most 256 threads (build.py: MC_WPB_C = MC_WPB_E = 4, the index kernels' 4).
+#define MC_INTERP_THREADS 256
+static_assert(64 * MC_WPB_C <= MC_INTERP_THREADS && 64 * MC_WPB_E <= MC_INTERP_THREADS && 64 * MC_WPB_ES <= MC_INTERP_THREADS,
+              "the interpreter's register file has one column per thread of a workgroup");
 __device__ __forceinline__ float mc_interp_run(const McInterpProg& P, float x, float y, float z) {
-    float r[MC_INTERP_REGS];
-#pragma unroll
-    for (int i = 0; i < MC_INTERP_REGS; ++i) r[i] = 0.0f;
+    __shared__ float s_ir[MC_INTERP_REGS + 3][MC_INTERP_THREADS];  // the registers, then x, y, z (a variable is an operand like a register)
+    float* r = &s_ir[0][threadIdx.x & (MC_INTERP_THREADS - 1)];
+#define MC_IR(i) r[(i) * MC_INTERP_THREADS]
+    MC_IR(MC_INTERP_REGS + 0) = x;
+    MC_IR(MC_INTERP_REGS + 1) = y;
+    MC_IR(MC_INTERP_REGS + 2) = z;
     auto fetch = [&](u32 o) -> float {
-        if (o < 64u) return r[o & (MC_INTERP_REGS - 1)];
-        if (o < 128u) return o == 64u ? x : o == 65u ? y : z;
+        if (o < 128u) return MC_IR(o < 64u ? (o & (MC_INTERP_REGS - 1)) : MC_INTERP_REGS + ((o - 64u) & 3u) % 3u);
         return P.cval[(o - 128u) & (MC_INTERP_CONSTS - 1)];
     };
     float last = fetch(P.root);
@@ -158,10 +168,11 @@ __device__ __forceinline__ float mc_interp_run(const McInterpProg& P, float x, f
             const float b = fetch(bo);
             v = op == 0u ? a + b : op == 1u ? a - b : op == 2u ? a * b : op == 3u ? a / b : mc_pow_general(a, b);
         }
-        r[d & (MC_INTERP_REGS - 1)] = v;
+        MC_IR(d & (MC_INTERP_REGS - 1)) = v;
         last = v;
     }
     return last;
+#undef MC_IR
 }
 __device__ __forceinline__ float mc_f(float x, float y, float z) { return mc_interp_run(c_interp.f, x, y, z); }
 #define MC_CONS 1
