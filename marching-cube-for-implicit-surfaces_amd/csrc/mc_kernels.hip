@@ -2354,16 +2354,23 @@ __device__ __forceinline__ int mc_edge_of(int ax, int d0, int d1) {
 // owner then follows from lattice indices alone, no sample of f, no interpolation
 __device__ __forceinline__ void mc_resolve(const McParams& p, const u8* __restrict__ codes, const u32* __restrict__ recs,
                                            const uint2* __restrict__ segcb, int ix, int iy, int iz, int e, int& qx, int& qy,
-                                           int& qz, int& qe, bool& corner, bool edge_key_known = false) {
+                                           int& qz, int& qe, bool& corner, bool edge_key_known = false, const float* cell6 = nullptr) {
     const float* __restrict__ axis = p.axis;
     const int ax = edge_axis(e);
     int b[3] = {ix + (int)((MC_EDGE_OX >> e) & 1u), iy + (int)((MC_EDGE_OY >> e) & 1u), iz + (int)((MC_EDGE_OZ >> e) & 1u)};
     int sn = 0;
     float v0 = 0.0f, v1 = 0.0f;
     if (!edge_key_known) {
-        const float x0 = axis[b[0]], y0 = axis[b[1]], z0 = axis[b[2]];
+        // cell6 = the cell's six lattice coordinates {x0, x1, y0, y1, z0, z1}, fetched once by the caller for all of the cell's
+        // edges: the same values the loads below return, without a memory round trip per edge (an edge's lower end has
+        // offset 0 on the edge's own axis)
+        // (selects with constant indices: a dynamically indexed private array would live in scratch)
+        const float x0 = cell6 ? (((MC_EDGE_OX >> e) & 1u) ? cell6[1] : cell6[0]) : axis[b[0]],
+                    y0 = cell6 ? (((MC_EDGE_OY >> e) & 1u) ? cell6[3] : cell6[2]) : axis[b[1]],
+                    z0 = cell6 ? (((MC_EDGE_OZ >> e) & 1u) ? cell6[5] : cell6[4]) : axis[b[2]];
         const int ba = ax == 0 ? b[0] : ax == 1 ? b[1] : b[2];
-        const float c0 = axis[ba], c1 = axis[ba + 1];
+        const float c0 = cell6 ? (ax == 0 ? cell6[0] : ax == 1 ? cell6[2] : cell6[4]) : axis[ba];
+        const float c1 = cell6 ? (ax == 0 ? cell6[1] : ax == 1 ? cell6[3] : cell6[5]) : axis[ba + 1];
         v0 = mc_F(p, x0, y0, z0);
         v1 = mc_F(p, ax == 0 ? c1 : x0, ax == 1 ? c1 : y0, ax == 2 ? c1 : z0);
         sn = mc_snap(p.iso, c0, c1, v0, v1);
@@ -2562,12 +2569,16 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
         if (valid && !((rec >> 17) & 7u)) recown[ridx] = 0u;  // seed mode: a cell outside the seed's component (no triangles left)
         if (valid && ((rec >> 17) & 7u)) {
             u32 m = crossed_edges((rec >> 8) & 0xFFu), cornm = 0;
+            // the cell's six lattice coordinates, once and together, for the snap test of every crossed edge (five loads and a
+            // memory round trip PER EDGE otherwise: the edge loop's iterations do not overlap)
+            float c6[6] = {p.axis[ix], p.axis[ix + 1], p.axis[iy], p.axis[iy + 1], p.axis[iz], p.axis[iz + 1]};
+            asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
             while (m) {
                 const int e = __builtin_ctz(m);
                 m &= m - 1u;
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner);
+                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner, false, c6);
                 if (qx == ix && qy == iy && qz == iz && qe == e) ownm |= 1u << e;
                 if (corner) cornm |= 1u << e;
             }

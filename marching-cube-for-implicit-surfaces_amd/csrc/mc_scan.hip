@@ -274,14 +274,20 @@ extern "C" __global__ __launch_bounds__(256) void mc_tnormal(const u32* __restri
     const u64 tri = (u64)blockIdx.x * 256ull + threadIdx.x;
     const u64 nt = (u64)total->x < cap_tris ? (u64)total->x : cap_tris;
     if (tri >= nt) return;
-    const u32 i1 = tlist[3ull * tri], i2 = tlist[3ull * tri + 1], i3 = tlist[3ull * tri + 2];
+    // (the loads of a level pinned together -- left alone the compiler fetches the three indices one after the other, each
+    // behind the range check of the one before: four memory round trips where two do)
+    u32 i1 = tlist[3ull * tri], i2 = tlist[3ull * tri + 1], i3 = tlist[3ull * tri + 2];
+    asm volatile("" : "+v"(i1), "+v"(i2), "+v"(i3));
     if (i1 >= nverts || i2 >= nverts || i3 >= nverts) {
         tnrm[tri] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
-    const float ax_ = vlist[3ull * i1], ay_ = vlist[3ull * i1 + 1], az_ = vlist[3ull * i1 + 2];
-    const float bax = vlist[3ull * i2] - ax_, bay = vlist[3ull * i2 + 1] - ay_, baz = vlist[3ull * i2 + 2] - az_;
-    const float cax = vlist[3ull * i3] - ax_, cay = vlist[3ull * i3 + 1] - ay_, caz = vlist[3ull * i3 + 2] - az_;
+    float ax_ = vlist[3ull * i1], ay_ = vlist[3ull * i1 + 1], az_ = vlist[3ull * i1 + 2];
+    float bx_ = vlist[3ull * i2], by_ = vlist[3ull * i2 + 1], bz_ = vlist[3ull * i2 + 2];
+    float cx_ = vlist[3ull * i3], cy_ = vlist[3ull * i3 + 1], cz_ = vlist[3ull * i3 + 2];
+    asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_), "+v"(bx_), "+v"(by_), "+v"(bz_), "+v"(cx_), "+v"(cy_), "+v"(cz_));
+    const float bax = bx_ - ax_, bay = by_ - ay_, baz = bz_ - az_;
+    const float cax = cx_ - ax_, cay = cy_ - ay_, caz = cz_ - az_;
     // glm::cross(x, y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
     tnrm[tri] = make_float4(bay * caz - cay * baz, baz * cax - caz * bax, bax * cay - cax * bay, 1.0f);
 }
