@@ -2762,15 +2762,24 @@ __device__ __forceinline__ u32 mc_find_record_opt(const McParams& p, const u32* 
 // take a second pass, one lane per vertex.
 #define MC_VN_CAP 256  // vertices of one kind (edge key / corner key) listed at a time; 16 records own at most 192
 // what cell (qx, qy, qz) adds to vertex v: its triangles in table order; out[t] = {cross(B-A, C-A), corners that are v}
-// The triangles of cell (qx, qy, qz) that have vertex v at a corner -> out[t] = {face normal, number of such corners}.
+// what one cell contributes to a vertex's sum: the face normals of the first two of its triangles that touch the vertex
+// (.w = how many corners of the triangle are the vertex, 0 = none), and -- rarely -- more of them (bit t of `more`; hp: two bits
+// per triangle, the corner count; t0: the cell's first triangle)
+struct McVnCell {
+    float4 a, b;
+    u32 more, hp, t0;
+};
+// The triangles of cell (qx, qy, qz) that have vertex v at a corner -> out (in triangle order: a, b, then `more`).
 // match_edge >= 0: v's key is a lattice EDGE, which is edge `match_edge` of this cell -- the cell's table row says which of its
 // triangles touch it, nothing is read from tri_list; match_edge < 0 (v is welded to a lattice corner, several edges lead to
 // it): the triangles' corner indices are compared with v.  The face normals come from mc_tnormal (mc_scan.hip).
 __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb,
                                            const u32* __restrict__ segtri, const u32* __restrict__ tlist, const float4* __restrict__ tnrm,
-                                           const u64* s_trirow, u64 cap_tris, int qx, int qy, int qz, u32 v, int match_edge, float4* out) {
-#pragma unroll
-    for (int t = 0; t < 5; ++t) out[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                           const u64* s_trirow, u64 cap_tris, int qx, int qy, int qz, u32 v, int match_edge, McVnCell& out) {
+    out.a = out.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    out.more = 0u;
+    out.hp = 0u;
+    out.t0 = 0u;
     // the cell's record: segment -> its records (ascending in x).  Four dependent loads fewer than a search that ends in the
     // record index: the segment's first triangle comes with its counts, up to four records are fetched at once and the one
     // wanted is picked (a segment of the sphere holds 1-3), longer segments are searched
@@ -2841,18 +2850,25 @@ __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restr
             hits[t] = wanted ? (ia[t] == v ? 1u : 0u) + (ib[t] == v ? 1u : 0u) + (ic[t] == v ? 1u : 0u) : 0u;
         }
     }
-    // the face normals of the triangles that touch the vertex (the others read triangle 0's, and drop it): one level
-    float4 fn[5];
+    // The face normals of the FIRST TWO triangles that touch the vertex, one level; a cell's triangles touch one of its edges
+    // once or twice, a third / fourth / fifth is left to the caller (out.more, in triangle order behind these two).  The
+    // kernel pays for every gather and for every slot of the sum's chain: five loads and five slots per cell, most of them
+    // empty, were a quarter of its time.
+    u32 hm = 0u;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         if ((u64)(t0 + (u32)t) >= cap_tris) hits[t] = 0u;
-        fn[t] = tnrm[hits[t] ? t0 + (u32)t : 0u];
+        hm |= hits[t] ? 1u << t : 0u;
+        out.hp |= hits[t] << (2 * t);
     }
-    MC_TOGETHER4(fn[0].x, fn[1].x, fn[2].x, fn[3].x);
-    MC_TOGETHER4(fn[4].x, fn[0].w, fn[1].w, fn[2].w);
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-        if (hits[t] && fn[t].w != 0.0f) out[t] = make_float4(fn[t].x, fn[t].y, fn[t].z, __builtin_bit_cast(float, hits[t]));
+    const u32 rest = hm & (hm - 1u);
+    const u32 ta = hm ? (u32)__builtin_ctz(hm) : 0u, tb = rest ? (u32)__builtin_ctz(rest) : 0u;
+    float4 fa = tnrm[hm ? t0 + ta : 0u], fb = tnrm[rest ? t0 + tb : 0u];
+    MC_TOGETHER4(fa.x, fa.w, fb.x, fb.w);
+    if (hm && fa.w != 0.0f) out.a = make_float4(fa.x, fa.y, fa.z, __builtin_bit_cast(float, (out.hp >> (2u * ta)) & 3u));
+    if (rest && fb.w != 0.0f) out.b = make_float4(fb.x, fb.y, fb.z, __builtin_bit_cast(float, (out.hp >> (2u * tb)) & 3u));
+    out.more = rest & (rest - 1u);
+    out.t0 = t0;
 #undef MC_TOGETHER2
 #undef MC_TOGETHER4
 }
@@ -2874,6 +2890,18 @@ __device__ __forceinline__ void mc_vn_add(const float4 c, float& sx, float& sy, 
         sx = c.x + sx;
         sy = c.y + sy;
         sz = c.z + sz;
+    }
+}
+// ... a whole cell's contribution, in triangle order
+__device__ __forceinline__ void mc_vn_add_cell(const McVnCell& c, const float4* __restrict__ tnrm, float& sx, float& sy, float& sz) {
+    mc_vn_add(c.a, sx, sy, sz);
+    mc_vn_add(c.b, sx, sy, sz);
+    u32 more = c.more;
+    while (more) {  // (a third, fourth, fifth triangle of one cell on one vertex: rare)
+        const u32 t = (u32)__builtin_ctz(more);
+        more &= more - 1u;
+        const float4 f = tnrm[c.t0 + t];
+        if (f.w != 0.0f) mc_vn_add(make_float4(f.x, f.y, f.z, __builtin_bit_cast(float, (c.hp >> (2u * t)) & 3u)), sx, sy, sz);
     }
 }
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McParams* __restrict__ P, const u32* __restrict__ recs,
@@ -2936,9 +2964,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
             // triangles to what the cells before it have summed -- the reference's additions in the reference's order, no LDS
             for (u32 k0 = 0; k0 < NE; k0 += 16u) {
                 const u32 k = k0 + ((u32)lane >> 2), j = (u32)lane & 3u;
-                float4 mine[5];
-#pragma unroll
-                for (int t = 0; t < 5; ++t) mine[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                McVnCell mine;
+                mine.a = mine.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                mine.more = mine.hp = mine.t0 = 0u;
                 u32 v = 0xFFFFFFFFu;
                 if (k < NE) {
                     const u32 it = item[k];
@@ -2960,10 +2988,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 #pragma unroll
                 for (u32 step = 0; step < 4u; ++step) {
-                    if (j == step) {
-#pragma unroll
-                        for (int t = 0; t < 5; ++t) mc_vn_add(mine[t], sx, sy, sz);
-                    }
+                    if (j == step) mc_vn_add_cell(mine, tnrm, sx, sy, sz);
                     if (step < 3u) {  // hand the sum to the next lane (row_shr:1; lanes 4 k .. 4 k + 3 sit in one DPP row)
                         const float tx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x111, 0xf, 0xf, false));
                         const float ty = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x111, 0xf, 0xf, false));
@@ -2999,10 +3024,9 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                 for (int dz = -1; dz <= (ax == 2 ? 1 : 0); ++dz)
                     for (int dy = -1; dy <= (ax == 1 ? 1 : 0); ++dy)
                         for (int dx = -1; dx <= (ax == 0 ? 1 : 0); ++dx) {
-                            float4 cc[5];
+                            McVnCell cc;
                             mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_trirow, cap_tris, bx + dx, by + dy, bz + dz, v, -1, cc);
-#pragma unroll
-                            for (int t = 0; t < 5; ++t) mc_vn_add(cc[t], sx, sy, sz);
+                            mc_vn_add_cell(cc, tnrm, sx, sy, sz);
                         }
                 if ((u64)v < nverts) {
                     const float d = (sx * sx + sy * sy) + sz * sz;
