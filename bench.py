@@ -110,6 +110,7 @@ def cold_start(mc_amd, device):
     context and an EMPTY code-object cache; wall-clock milliseconds of mc_march at grid_res 32, outside the timed region."""
     import tempfile
     old = os.environ.get("MC_JIT_CACHE")
+    old_cold = os.environ.pop("MC_COLD_START", None)   # (MC_COLD_START=jit would make every first sweep wait for hiprtc: not what is measured here)
     out = {"grid_res": 32, "reference_s": 0.095, "reference_source": "BASELINE.md section 2 (sphere, grid_res 32, one CPU thread)"}
     with tempfile.TemporaryDirectory() as d:
         os.environ["MC_JIT_CACHE"] = d
@@ -139,6 +140,8 @@ def cold_start(mc_amd, device):
             out["first_mesh_ms_waiting_for_hiprtc"] = round((time.perf_counter() - t0) * 1e3, 1)
         finally:
             c.close()
+            if old_cold is not None:
+                os.environ["MC_COLD_START"] = old_cold
             if old is None:
                 os.environ.pop("MC_JIT_CACHE", None)
             else:

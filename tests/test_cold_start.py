@@ -102,6 +102,7 @@ def test_first_mesh_of_an_unseen_equation(mc, orc, tmp_path):
     specialised kernels take over (interpreted = 0) with the same bytes.  The same for Evaluator::evaluate (mc_eval_points)
     and for the facade's default, the indexed mesh.  Timings are reported by bench.py; here only a loose bound."""
     old = os.environ.get("MC_JIT_CACHE")
+    old_cold = os.environ.pop("MC_COLD_START", None)     # (tests/conftest.py makes the rest of the suite wait for hiprtc)
     os.environ["MC_JIT_CACHE"] = str(tmp_path)
     c = mc.Context(0)
     try:
@@ -147,6 +148,8 @@ def test_first_mesh_of_an_unseen_equation(mc, orc, tmp_path):
         assert c.graph_replay(0.0).interpreted == 0
     finally:
         c.close()
+        if old_cold is not None:
+            os.environ["MC_COLD_START"] = old_cold
         if old is None:
             os.environ.pop("MC_JIT_CACHE", None)
         else:

@@ -745,9 +745,19 @@ def test_random_expressions_match_the_oracle(mc, orc, seed):
     try:
         r = c.march(eq, step, iso, scale)
         o = orc.march(eq, step, iso, scale, pow_mode=orc.POW_EXACT, want=3)
+        assert r.interpreted == 0                                  # (the specialised kernels: tests/conftest.py)
         assert np.array_equal(r.codes(), o.codes), eq
         assert (r.n_tris, r.n_active) == (o.n_tris, o.n_active), eq
-        assert_same_floats(r.vertices()[:, :, :3], o.soup, eq)
+        rv = r.vertices()
+        assert_same_floats(rv[:, :, :3], o.soup, eq)
+        # ... and the interpreter build of the same kernels (what an unseen equation's first sweeps run on): the same bytes
+        try:
+            ri = c.march(eq, step, iso, scale, flags=mc.FLAG_NORMALS | mc.FLAG_KEEP_CODES | mc.FLAG_INTERP)
+        except mc.McError as e:
+            assert e.code == mc.MC_ERR_ARG and "too long" in str(e), eq   # (beyond the interpreter's tables: it says so)
+        else:
+            assert ri.interpreted == 1 and np.array_equal(ri.codes(), o.codes), eq
+            assert_same_floats(ri.vertices()[:, :, :3], rv[:, :, :3], "interpreter build: " + eq)
     finally:
         c.close()
 
