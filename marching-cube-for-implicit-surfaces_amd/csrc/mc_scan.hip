@@ -407,8 +407,26 @@ __device__ __forceinline__ bool cc_mixed(u32 code, u32 face) { return (code & fa
 // wave has nothing else to do meanwhile -- issued together they cost one chain, not two
 __device__ __forceinline__ void cc_lookup2(const u32* __restrict__ recs, const uint2* __restrict__ segcb, bool wa, u32 sega, bool wb, u32 segb,
                                            u32 cellx, u32& ra, u32& rb) {
-    const uint2 ca = wa ? segcb[sega] : make_uint2(0u, 0u), cb = wb ? segcb[segb] : make_uint2(0u, 0u);
+    // (every level's loads pinned together: the compiler otherwise puts each load behind the condition that guards it and
+    // the two look-ups run one after the other, load by load -- seen in the ISA: 33 loads, 33 waits in mc_cc_link)
+    uint2 ca = segcb[wa ? sega : 0u], cb = segcb[wb ? segb : 0u];
+    asm volatile("" : "+v"(ca.x), "+v"(ca.y), "+v"(cb.x), "+v"(cb.y));
+    if (!wa) ca = make_uint2(0u, 0u);
+    if (!wb) cb = make_uint2(0u, 0u);
     const u32 acta = ca.x >> 16, actb = cb.x >> 16;
+    if (acta <= 4u && actb <= 4u) {
+        // the common case (a segment of a curved surface holds 1-3 records): the first four records of both segments at
+        // once, the one wanted picked -- one round trip instead of a binary search's two or three (the record buffer has
+        // slack behind its last record: mc_runtime.hip MC_REC_SLACK_BYTES)
+        u32 a0 = recs[ca.y], a1 = recs[ca.y + 1u], a2 = recs[ca.y + 2u], a3 = recs[ca.y + 3u];
+        u32 b0 = recs[cb.y], b1 = recs[cb.y + 1u], b2 = recs[cb.y + 2u], b3 = recs[cb.y + 3u];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        ra = (acta > 0u && (a0 & 0xFFu) == cellx) ? ca.y : (acta > 1u && (a1 & 0xFFu) == cellx) ? ca.y + 1u
+             : (acta > 2u && (a2 & 0xFFu) == cellx) ? ca.y + 2u : (acta > 3u && (a3 & 0xFFu) == cellx) ? ca.y + 3u : 0xFFFFFFFFu;
+        rb = (actb > 0u && (b0 & 0xFFu) == cellx) ? cb.y : (actb > 1u && (b1 & 0xFFu) == cellx) ? cb.y + 1u
+             : (actb > 2u && (b2 & 0xFFu) == cellx) ? cb.y + 2u : (actb > 3u && (b3 & 0xFFu) == cellx) ? cb.y + 3u : 0xFFFFFFFFu;
+        return;
+    }
     u32 loa = 0u, hia = acta, lob = 0u, hib = actb;
     while (loa < hia || lob < hib) {
         const u32 ma = (loa + hia) >> 1, mb = (lob + hib) >> 1;
@@ -660,11 +678,19 @@ extern "C" __global__ __launch_bounds__(256) void mc_cc_link(const u32* __restri
         const u32 none = 0xFFFFFFFFu;
         // (plain loads: a value that is out of date is still an ancestor -- mc_cc_local's, from the launch before, or a
         // later one -- and the test only ever PRUNES a union when two ancestors are equal, i.e. the sets were one already)
+        // The four loads travel TOGETHER (a link that does not exist reads the record's own parent instead, and drops it):
+        // left to itself the compiler puts each load behind the branch that guards it, four memory round trips in a row.
         const u32* __restrict__ pplain = parent;
-        const u32 pm = valid ? pplain[r] : none;
-        const u32 px = rx != none ? pplain[rx] : none;
-        const u32 py = ry != none ? pplain[ry] : none;
-        const u32 pz = rz != none ? pplain[rz] : none;
+        const u32 rsafe = valid ? r : 0u;
+        u32 pm = pplain[rsafe];
+        u32 px = pplain[rx != none ? rx : rsafe];
+        u32 py = pplain[ry != none ? ry : rsafe];
+        u32 pz = pplain[rz != none ? rz : rsafe];
+        asm volatile("" : "+v"(pm), "+v"(px), "+v"(py), "+v"(pz));
+        pm = valid ? pm : none;
+        px = rx != none ? px : none;
+        py = ry != none ? py : none;
+        pz = rz != none ? pz : none;
         const bool ux = cc_leader(s_tab[w], s_key[w], lane, rx != none, pm, px);
         const bool uy = cc_leader(s_tab[w], s_key[w], lane, ry != none, pm, py);
         const bool uz = cc_leader(s_tab[w], s_key[w], lane, rz != none, pm, pz);
