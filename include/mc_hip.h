@@ -249,7 +249,7 @@ int mc_set_constraint(mc_context *ctx, int i, const char *lhs, const char *op, f
  * last cell whose centre lies inside [-1,1] (:84-86).  Differences, DESIGN.md: cells are the dense sweep's lattice cells
  * (the reference re-derives their positions as -1 + k*step, a few ulp off), and the triangles come in sweep order, not in
  * breadth-first order.  (That set is a connected component of the surface cells; it is labelled on the device by a
- * union-find over the sweep's records, not walked.)  Whole-grid sweeps only (z_begin 0, z_end -1); not capturable by
+ * union-find over the sweep's records, not walked.)  Whole-grid sweeps only (z_begin 0, z_end -1); capturable by
  * mc_graph_build.  With MC_FLAG_INDEXED the component is welded like the dense sweep (only visited cells insert
  * vertices, marching.cpp:310-331): the reference numbers vertices and triangles in VISITATION order and keeps the position
  * computed by the first visited cell of each vertex; here both follow the sweep order -- the same triangles over the same
@@ -268,8 +268,9 @@ int mc_cells_per_axis(float step);
  *    that re-targets or re-allocates a buffer, mc_set_constraint / mc_use_constraint -- makes the next replay re-capture
  *    the ORIGINAL sweep first (never another equation's kernels on this one's buffers).  MC_FLAG_INDEXED (with or without
  *    MC_FLAG_SEAM) is captured too: its five kernels follow the sweep's in the graph, the index buffers get head room at
- *    capture time, and a frame that outgrows them is run again by mc_graph_wait / mc_graph_replay.  Seed mode sizes its
- *    component buffers from the host between kernels and is refused by mc_graph_build. */
+ *    capture time, and a frame that outgrows them is run again by mc_graph_wait / mc_graph_replay.  Seed mode is captured
+ *    too (the component-labelling kernels become nodes of the graph; the seed is part of the capture: mc_set_seed /
+ *    mc_seed_mode make the next replay re-capture). */
 int mc_graph_build(mc_context *ctx, const mc_params *p);
 int mc_graph_replay(mc_context *ctx, float iso, mc_result *res);
 /* The same without the host round trip: enqueue one replay and return; mc_graph_wait blocks until everything enqueued

@@ -659,8 +659,42 @@ def test_seed_mode_errors(mc):
         c.seed_mode(True)
         with pytest.raises(mc.McError):
             c.march(EQ["sphere"], step_of(32), z_begin=0, z_end=10)     # whole grid only
-        with pytest.raises(mc.McError):
-            c.graph_build(EQ["sphere"], step_of(32))
+    finally:
+        c.close()
+
+
+def test_seed_mode_in_a_captured_graph(mc, orc):
+    """Seed mode is capturable (round 4): the component-labelling kernels are nodes of the graph.  An iso sweep in seed mode
+    -- two sheets, the seed on one of them -- replayed from one capture equals the un-captured seed-mode sweep frame by
+    frame (bytes), soup and welded; moving the seed to the other sheet, or turning seed mode off, makes the next replay
+    re-capture (the seed's cell is baked into the captured kernels' arguments)."""
+    eq, step = "x^2-0.25", step_of(48)
+    c = mc.Context(0)
+    try:
+        # the seed's cell is x in [0.5, 0.5417): the sheet x = sqrt(0.25 + iso) stays inside it for the first four iso values
+        # and leaves it for the fifth (a seed cell without a crossing: an empty mesh, marching.cpp:310-331)
+        c.set_seed(0.52, 0.0, 0.0)
+        c.seed_mode(True)
+        for flags in (mc.FLAG_NORMALS, mc.FLAG_INDEXED | mc.FLAG_NO_EMIT):
+            c.graph_build(eq, step, iso=0.02, flags=flags)
+            for iso in (0.02, 0.03, 0.011, 0.02, 0.2, 0.03):
+                g = c.graph_replay(iso)
+                got = g.indexed() if flags & mc.FLAG_INDEXED else (g.vertices(),)
+                m = c.march(eq, step, iso, flags=flags)
+                want = m.indexed() if flags & mc.FLAG_INDEXED else (m.vertices(),)
+                assert g.n_tris == m.n_tris and (g.n_tris > 0) == (iso != 0.2)
+                for x, y in zip(got, want):
+                    assert np.array_equal(u32(x) if x.dtype == np.float32 else x, u32(y) if y.dtype == np.float32 else y)
+                dense_tris = orc.march(eq, step, iso, pow_mode=orc.POW_EXACT, want=0).n_tris
+                assert g.n_tris < dense_tris        # one sheet of the two
+        c.graph_build(eq, step, iso=0.02)
+        a = c.graph_replay(0.02).vertices()
+        c.set_seed(-0.52, 0.0, 0.0)                   # the other sheet
+        b = c.graph_replay(0.02).vertices()
+        assert a.shape == b.shape and len(a) > 0 and a[:, :, 0].min() > 0 and b[:, :, 0].max() < 0
+        c.seed_mode(False)
+        d = c.graph_replay(0.02)
+        assert d.n_tris == orc.march(eq, step, 0.02, pow_mode=orc.POW_EXACT, want=0).n_tris > len(a)    # (the dense sweep also has the tail plane of cells)
     finally:
         c.close()
 
