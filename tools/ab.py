@@ -8,7 +8,8 @@ SPEC is a `;`-separated list of
     patch:FILE             a file of text replacements applied to the kernel source (MC_JIT_PATCH; tools/probes/*.patch:
                            blocks  OLD / a line "====" / NEW  separated by lines "@@@@") -- the timing probes
                            ("what if this phase did nothing") live there, not in the shipped kernels
-    env:NAME=VALUE         an environment variable of the developer build (MC_WPB_EMIT, MC_WPB_CLASSIFY, MC_TILE_H ...)
+    env:NAME=VALUE         an environment variable of the developer build (MC_WPB_EMIT, MC_WPB_CLASSIFY, MC_TILE_H ...;
+                           MC_JIT_OPTS=further hiprtc options, e.g. `-mllvm -amdgpu-sched-strategy=max-ilp`)
 An empty SPEC is the default build.  Everything runs against libmc_hip_dev.so (MC_AMD_DEV_LIB=1); the shipped
 libmc_hip.so honours none of these hooks."""
 import json
