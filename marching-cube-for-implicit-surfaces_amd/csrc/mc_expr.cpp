@@ -742,28 +742,32 @@ std::string emit_hip_interval(const Program& p, const char* fname) {
     return s;
 }
 
-// The same enclosure in two stages, for the classify walk: the sub-expressions that depend on y ONLY and are expensive
-// (sin / cos, divisions, higher powers) are evaluated once per tile row (mc_f_iv_y, lane = row) and the rest per lane
-// box from those values (mc_f_iv_rest).  The walk's x and z boxes do not change from row to row, so the compiler hoists
-// their share by itself; y's it cannot (the row is a loop variable).  "" when nothing is worth staging.
+// The same enclosure in two stages, for the classify walk: the sub-expressions that do NOT depend on x, depend on y and are
+// expensive in their y part (sin / cos, divisions, higher powers of y -- alone or combined with anything of z: the gyroid's
+// sin(y)*cos(z)) are evaluated once per tile row (mc_f_iv_y, lane = row: the tile's z box is the same for every row) and the
+// rest per lane box from those values (mc_f_iv_rest).  The walk's x and z boxes do not change from row to row, so the
+// compiler hoists what depends on them alone by itself; what depends on y it cannot (the row is a loop variable).  Round 4:
+// "y only" became "not x" -- the product sin(y)*cos(z) used to be an interval product per lane and row step.  "" when
+// nothing is worth staging.
 std::string emit_hip_interval_staged(const Program& p, int min_cost) {
     const size_t n = p.nodes.size();
-    std::vector<char> used_outside(n, 0);   // some user depends on more than y, or the node is the root
+    auto xfree_y = [&](const Node& nd) { return (nd.deps & 1) == 0 && (nd.deps & 2) != 0; };
+    std::vector<char> used_outside(n, 0);   // some user depends on x (or does not depend on y), or the node is the root
     for (size_t i = 0; i < n; ++i) {
         const Node& nd = p.nodes[i];
-        if (nd.deps == 2) continue;
+        if (xfree_y(nd)) continue;
         if (nd.a >= 0) used_outside[nd.a] = 1;
         if (nd.b >= 0) used_outside[nd.b] = 1;
     }
     used_outside[p.root] = 1;
-    // cost of a node's whole y-only cone (each node once)
+    // a node's whole cone (each node once); its cost: the nodes that depend on y -- what a row step would pay for it
     auto cone = [&](size_t root, std::vector<char>& in) {
         in.assign(n, 0);
         in[root] = 1;
         int c = 0;
         for (size_t i = root + 1; i-- > 0;) {
             if (!in[i]) continue;
-            c += iv_node_cost(p.nodes[i]);
+            if (p.nodes[i].deps & 2) c += iv_node_cost(p.nodes[i]);
             if (p.nodes[i].a >= 0) in[p.nodes[i].a] = 1;
             if (p.nodes[i].b >= 0) in[p.nodes[i].b] = 1;
         }
@@ -773,14 +777,14 @@ std::string emit_hip_interval_staged(const Program& p, int min_cost) {
     std::vector<char> in, ystage(n, 0);
     for (size_t i = 0; i < n; ++i) {
         const Node& nd = p.nodes[i];
-        if (nd.deps != 2 || !used_outside[i] || nd.op == NodeOp::VARY) continue;
+        if (!xfree_y(nd) || !used_outside[i] || nd.op == NodeOp::VARY) continue;
         if (cone(i, in) < min_cost) continue;
         hoisted.push_back((int)i);
         for (size_t k = 0; k < n; ++k) ystage[k] = ystage[k] | in[k];
     }
     if (hoisted.empty() || hoisted.size() > 8) return std::string();
     std::string s = "#define MC_IV_NY " + std::to_string(2 * hoisted.size()) + "\n";
-    s += "__device__ __forceinline__ void mc_f_iv_y(float yl, float yh, float (&Y)[MC_IV_NY]) {\n";
+    s += "__device__ __forceinline__ void mc_f_iv_y(float yl, float yh, float zl, float zh, float (&Y)[MC_IV_NY]) {\n    (void)zl; (void)zh;\n";
     for (size_t i = 0; i < n; ++i)
         if (ystage[i] && !iv_node(p, i, s)) return std::string();
     for (size_t k = 0; k < hoisted.size(); ++k)

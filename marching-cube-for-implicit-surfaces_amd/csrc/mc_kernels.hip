@@ -1218,7 +1218,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_C, MC_CLASSIFY_MINW) void mc
         {
             const float y1 = __shfl_down(yv, 1, 64), y2 = __shfl_down(yv, 2, 64);
             const float yt = pairL ? y2 : y1;
-            mc_f_iv_y(__builtin_fminf(yv, yt), __builtin_fmaxf(yv, yt), Yv);
+            mc_f_iv_y(__builtin_fminf(yv, yt), __builtin_fmaxf(yv, yt), zl, zh, Yv);
         }
         const u64 pairs = __ballot(pairL);
         u64 mu = __ballot(headL);

@@ -50,7 +50,7 @@ int main() {
         mc_f_iv(b[0], b[1], b[2], b[3], b[4], b[5], lo, hi);
 #ifdef MC_IV_NY
         float Y[MC_IV_NY], lo2, hi2;
-        mc_f_iv_y(b[2], b[3], Y);
+        mc_f_iv_y(b[2], b[3], b[4], b[5], Y);
         mc_f_iv_rest(b[0], b[1], b[2], b[3], b[4], b[5], Y, lo2, hi2);
         if (std::memcmp(&lo, &lo2, 4) || std::memcmp(&hi, &hi2, 4)) ++bad_stage;
 #endif
@@ -133,7 +133,7 @@ def trig(mc):
 @pytest.mark.parametrize("eq", STAGED)
 def test_staged_enclosure_equals_whole_and_encloses(mc, trig, tmp_path, eq):
     ny, bad_stage, bad_encl = run_host(mc, tmp_path, eq, 2.0)
-    assert ny >= 2 and ny % 2 == 0          # one [lo, hi] pair per hoisted sub-expression of y
+    assert ny >= 2 and ny % 2 == 0          # one [lo, hi] pair per hoisted sub-expression (of y, or of y and z)
     assert bad_stage == 0 and bad_encl == 0
 
 
