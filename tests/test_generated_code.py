@@ -17,7 +17,9 @@ from conftest import ROOT
 
 GYROID = "sin(x)*cos(y)+sin(y)*cos(z)+sin(z)*cos(x)"
 STAGED = [GYROID, "sin(3y)*x+z*z-0.2", "x^2+z^2-1/(y*y+1.5)", "x*y^5+z^2-0.3", "cos(y)+cos(2y)*x-z", "sin(x)+sin(y)+sin(z)",
-          "x/(y+3)+y^4*z-0.1", "x*x+z+((y-2.5)^-3)*cos(y)"]
+          "x/(y+3)+y^4*z-0.1", "x*x+z+((y-2.5)^-3)*cos(y)",
+          # round 4: sub-expressions WITHOUT x (of y and z together) are staged too -- the second one only through its product
+          "sin(y)*cos(z)+x*0.5", "x+y^3*z^3"]
 NOT_STAGED = ["x^2+y^2+z^2-1", "x*y+z", "x*x+z+(y-2.5)^-3", "sin(x)*y+z"]
 
 HARNESS = r'''
@@ -150,8 +152,10 @@ def test_gyroid_stages_sin_and_cos_of_y(mc, trig):
     assert "#define MC_IV_NY 4" in src
     ypart = src[src.index("void mc_f_iv_y("):src.index("void mc_f_iv_rest(")]
     assert ypart.count("mc_sin_iv(yl, yh") == 1 and ypart.count("mc_cos_iv(yl, yh") == 1
+    assert ypart.count("mc_cos_iv(zl, zh") == 1      # sin(y)*cos(z) as a whole: one interval product per tile row
     rest = src[src.index("void mc_f_iv_rest("):]
     assert "yl" not in rest.split("{", 1)[1].replace("(void)yl; (void)yh;", "")   # the rest reads y only through Y[]
+    assert rest.count("mc_cos_iv(") == 1 and rest.count("mc_sin_iv(") == 2        # cos x; sin x, sin z
 
 
 TABULATED = [GYROID, "sin(3y)*x+z*z-0.2", "x^2+z^2-1/((y*y+1.5)^3)", "x*y^5+z^2-0.3", "sin(x)*sin(y)*sin(z)+sin(x)*cos(y)*cos(z)",
