@@ -404,6 +404,7 @@ RATIONAL = {
     "div_zero": "x/y+z",                         # divisor crosses 0: sampling fallback, inf/nan samples
     "div_y": "x^2+z^2-1/(y*y+1.5)",              # expensive sub-expression of y alone: the staged enclosure (mc_f_iv_y)
     "pow_y": "x*y^5+z^2-0.3",                    # same, a power
+    "pow_yz": "x+y^3*z^3*4-0.1",                 # a sub-expression of y AND z (no x): staged as a whole (round 4)
 }
 
 
@@ -422,7 +423,7 @@ EQ_ALL = dict(EQ, **RATIONAL)
                                         ("eq6", 64, 0.0), ("goursat", 96, -0.4), ("ui_default", 40, 0.0),
                                         ("div_pos", 64, 0.0), ("div_lin", 64, 0.0), ("negpow", 64, 0.0),
                                         ("negpow_odd", 64, 0.0), ("div_var", 64, 0.0), ("div_y", 64, 0.0), ("pow_y", 96, 0.0),
-                                        ("div_y", 300, 0.0)])
+                                        ("div_y", 300, 0.0), ("pow_yz", 96, 0.0), ("pow_yz", 300, 0.0)])
 def test_interval_row_culling_is_exact(mc, ctx, name, n, iso):
     """K1 proves rows / lanes uniform with interval arithmetic (mc_f_iv) and never samples them; the kernels
     compiled with the interval walk left out (MC_FLAG_NO_CULL: the sampling walk) must give byte-identical codes
