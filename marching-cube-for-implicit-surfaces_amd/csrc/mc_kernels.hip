@@ -2227,7 +2227,6 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     // The next chunk is taken -- and its records are requested -- BEFORE the current chunk's vertices are stored: vmcnt
     // retires in order, so the load is back long before the stores have drained, and the wave never waits a memory round
     // trip between two chunks.
-    int dw = 0;  // the group this wave is taking chunks from: (w + dw) mod MC_WPB_E (MC_WPB_E is a power of two)
     struct Unit {
         int wv;        // whose group
         u32 r0, nrec;  // first record of the chunk, records of the group
@@ -2236,8 +2235,16 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_E) void mc_emit_direct(const
     auto take = [&](Unit& u) __attribute__((always_inline)) {
         u.rec = 0u;
         u.lo = 0u;
-        for (; dw < MC_WPB_E; ++dw) {
-            u.wv = (w + dw) & (MC_WPB_E - 1);
+        // which groups of the workgroup still hold a chunk nobody has taken: lane i looks at group (w + i) mod MC_WPB_E (a
+        // power of two), the wave's own first.  The counters only grow: a group seen exhausted stays so, one seen open may be
+        // gone by the time of the atomic.  (Round 4: walking the groups one by one, an LDS atomic and a read each, cost a
+        // wave eight dependent LDS round trips before it could leave.)
+        const int gi = (w + lane) & (MC_WPB_E - 1);
+        u64 cand = __ballot(lane < MC_WPB_E && s_next[gi] < s_act[gi][64]);
+        while (cand) {
+            const int di = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            u.wv = (w + di) & (MC_WPB_E - 1);
             const u32* actoff = s_act[u.wv];
             u.nrec = actoff[64];
             u32 r0 = 0u;
