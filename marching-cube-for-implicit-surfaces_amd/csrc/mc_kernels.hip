@@ -290,6 +290,25 @@ struct McParams {
 #endif
 
 __device__ __constant__ u64 c_tri_row[256] = MC_TRI_ROW_INIT;       // marching_lookup.h:64-320, nibble-packed
+// per (row, edge) one byte: bit t = triangle t of the row has a corner on that edge -- derived from the rows at compile time
+// (mc_vnormal: which of a cell's triangles touch a vertex's lattice edge)
+struct McEdgeTri {
+    u32 w[256 * 12 / 4];
+    constexpr McEdgeTri() : w{} {
+        constexpr u64 rows[256] = MC_TRI_ROW_INIT;
+        for (int i = 0; i < 256 * 12; ++i) {
+            const u64 tr = rows[i / 12];
+            const u32 e = (u32)(i % 12);
+            u32 m = 0u;
+            for (int t = 0; t < 5; ++t) {
+                const u32 trip = (u32)(tr >> (12 * t)) & 0xFFFu;  // (0xF ends the row: no edge has that number)
+                if ((trip & 15u) == e || ((trip >> 4) & 15u) == e || (trip >> 8) == e) m |= 1u << t;
+            }
+            w[i / 4] |= m << (8 * (i % 4));
+        }
+    }
+};
+__device__ __constant__ McEdgeTri c_edgetri = McEdgeTri();
 __device__ __constant__ u8 c_tri_count[256] = MC_TRI_COUNT_INIT;
 __device__ __constant__ u8 c_amb_face[256] = MC_AMB_FACE_INIT;      // :329-587 (alt row is always 255-c)
 __device__ __constant__ unsigned short c_face_corner[6] = MC_FACE_CORNER_INIT;  // :25-32
@@ -2782,7 +2801,8 @@ struct McVnCell {
 // it): the triangles' corner indices are compared with v.  The face normals come from mc_tnormal (mc_scan.hip).
 __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb,
                                            const u32* __restrict__ segtri, const u32* __restrict__ tlist, const float4* __restrict__ tnrm,
-                                           const u64* s_trirow, u64 cap_tris, int qx, int qy, int qz, u32 v, int match_edge, McVnCell& out) {
+                                           const u8* s_edgetri, u64 cap_tris, int qx, int qy, int qz, u32 v, int match_edge,
+                                           McVnCell& out) {
     out.a = out.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     out.more = 0u;
     out.hp = 0u;
@@ -2826,16 +2846,19 @@ __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restr
     }
     const u32 nt = (rec >> 17) & 7u;
     const u32 t0 = st + (rec >> 20);
-    u32 hits[5];
+    u32 hm = 0u;
     if (match_edge >= 0) {
+        // which of the cell's triangles touch that edge: one byte per (table row, edge), made once per workgroup (mc_vnormal).
+        // (Comparing the row's fifteen nibbles with the edge here, per cell and round, was a sixth of the kernel's vector
+        // instructions -- and those are what bounds it, round 4.)  A triangle touches an edge once.
         const u32 code = (rec >> 8) & 0xFFu;
-        const u64 tr = s_trirow[((rec >> 16) & 1u) ? 255u - code : code];  // marching.cpp:542-547
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const u32 trip = (u32)(tr >> (12 * t)) & 0xFFFu, e = (u32)match_edge;
-            hits[t] = (u32)t < nt ? ((trip & 15u) == e ? 1u : 0u) + (((trip >> 4) & 15u) == e ? 1u : 0u) + ((trip >> 8) == e ? 1u : 0u) : 0u;
-        }
+        hm = s_edgetri[(((rec >> 16) & 1u) ? 255u - code : code) * 12u + (u32)match_edge];  // marching.cpp:542-547
+        const u64 room = cap_tris > (u64)t0 ? cap_tris - (u64)t0 : 0ull;  // triangles beyond the buffer's capacity do not exist
+        if (room < 5ull) hm &= (1u << (u32)room) - 1u;
+        hm &= (1u << nt) - 1u;  // (seed mode: a record outside the seed's component keeps its code and has no triangles)
+        out.hp = (hm & 1u) | ((hm & 2u) << 1) | ((hm & 4u) << 2) | ((hm & 8u) << 3) | ((hm & 16u) << 4);
     } else {
+        u32 hits[5];
         // (every triangle's three indices, wanted or not -- triangle 0 of the list stands in for the ones that are not, its
         // line is in every lane's cache --, so that the fifteen loads are one level)
         u32 ia[5], ib[5], ic[5];
@@ -2856,18 +2879,16 @@ __device__ __forceinline__ void mc_vn_cell(const McParams& p, const u32* __restr
             const bool wanted = (u32)t < nt && (u64)(t0 + (u32)t) < cap_tris;
             hits[t] = wanted ? (ia[t] == v ? 1u : 0u) + (ib[t] == v ? 1u : 0u) + (ic[t] == v ? 1u : 0u) : 0u;
         }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            hm |= hits[t] ? 1u << t : 0u;
+            out.hp |= hits[t] << (2 * t);
+        }
     }
     // The face normals of the FIRST TWO triangles that touch the vertex, one level; a cell's triangles touch one of its edges
     // once or twice, a third / fourth / fifth is left to the caller (out.more, in triangle order behind these two).  The
     // kernel pays for every gather and for every slot of the sum's chain: five loads and five slots per cell, most of them
     // empty, were a quarter of its time.
-    u32 hm = 0u;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        if ((u64)(t0 + (u32)t) >= cap_tris) hits[t] = 0u;
-        hm |= hits[t] ? 1u << t : 0u;
-        out.hp |= hits[t] << (2 * t);
-    }
     const u32 rest = hm & (hm - 1u);
     const u32 ta = hm ? (u32)__builtin_ctz(hm) : 0u, tb = rest ? (u32)__builtin_ctz(rest) : 0u;
     float4 fa = tnrm[hm ? t0 + ta : 0u], fb = tnrm[rest ? t0 + tb : 0u];
@@ -2911,6 +2932,44 @@ __device__ __forceinline__ void mc_vn_add_cell(const McVnCell& c, const float4* 
         if (f.w != 0.0f) mc_vn_add(make_float4(f.x, f.y, f.z, __builtin_bit_cast(float, (c.hp >> (2u * t)) & 3u)), sx, sy, sz);
     }
 }
+// The same for the lanes where `on` holds, written WITHOUT lane-dependent control flow: the sum of an edge-keyed vertex
+// travels through the four lanes of its cells (mc_vnormal), one lane adding per step, and as branches every step cost the wave
+// the whole of mc_vn_add_cell -- four times ~95 instructions per round of 16 vertices, half of the kernel, which is bound by
+// its vector instructions (SQ_ACTIVE_INST_VALU = 0.37 of its 0.49 ms per SIMD, round 4).  A lane that does not add adds +0.0f:
+// x + 0.0f is x for every x the sum can hold (it starts at +0.0f and round-to-nearest never makes it -0.0f; NaN and inf
+// stay), so the bits are the reference's.  A second / third hit of one triangle and a third triangle of one cell are rare:
+// those parts run only when some lane of the wave needs them.
+__device__ __forceinline__ void mc_vn_add_masked(bool on, const float4 c, float& sx, float& sy, float& sz) {
+    const u32 hits = on ? __builtin_bit_cast(u32, c.w) : 0u;
+    {
+        const bool h = hits >= 1u;
+        sx = (h ? c.x : 0.0f) + sx;
+        sy = (h ? c.y : 0.0f) + sy;
+        sz = (h ? c.z : 0.0f) + sz;
+    }
+    if (__ballot(hits >= 2u)) {  // (wave-uniform)
+        const bool h2 = hits >= 2u, h3 = hits >= 3u;
+        sx = (h2 ? c.x : 0.0f) + sx;
+        sy = (h2 ? c.y : 0.0f) + sy;
+        sz = (h2 ? c.z : 0.0f) + sz;
+        sx = (h3 ? c.x : 0.0f) + sx;
+        sy = (h3 ? c.y : 0.0f) + sy;
+        sz = (h3 ? c.z : 0.0f) + sz;
+    }
+}
+__device__ __forceinline__ void mc_vn_add_cell_masked(bool on, const McVnCell& c, const float4* __restrict__ tnrm, float& sx, float& sy, float& sz) {
+    mc_vn_add_masked(on, c.a, sx, sy, sz);
+    mc_vn_add_masked(on, c.b, sx, sy, sz);
+    if (__ballot(on && c.more != 0u)) {  // (wave-uniform; a third, fourth, fifth triangle of one cell on one vertex: rare)
+        u32 more = on ? c.more : 0u;
+        while (more) {
+            const u32 t = (u32)__builtin_ctz(more);
+            more &= more - 1u;
+            const float4 f = tnrm[c.t0 + t];
+            if (f.w != 0.0f) mc_vn_add(make_float4(f.x, f.y, f.z, __builtin_bit_cast(float, (c.hp >> (2u * t)) & 3u)), sx, sy, sz);
+        }
+    }
+}
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                         const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                         const u32* __restrict__ recown, const u32* __restrict__ recvb,
@@ -2918,8 +2977,11 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                                                                         const float4* __restrict__ tnrm, float* __restrict__ vnrm, u64 nverts,
                                                                         u64 cap_tris) {
     // (LDS is what limits the waves per CU here, and the kernel lives on them: 71 % of its wave-cycles are waits for loads)
-    __shared__ u64 s_trirow[256];  // the case table's rows (marching_lookup.h:64-320, nibble-packed): which triangles of a cell touch an edge
-    for (int i = (int)threadIdx.x; i < 256; i += 64 * MC_WPB_I) s_trirow[i] = c_tri_row[i];  // (in front of the macro's barrier)
+    // per (case-table row, edge): bit t = triangle t of the row has a corner on that edge (mc_vn_cell; c_edgetri: made at compile
+    // time from marching_lookup.h:64-320's rows); filled in front of the macro's barrier
+    __shared__ u32 s_edgetri32[256 * 12 / 4];
+    for (int i = (int)threadIdx.x; i < 256 * 12 / 4; i += 64 * MC_WPB_I) s_edgetri32[i] = c_edgetri.w[i];
+    const u8* s_edgetri = (const u8*)s_edgetri32;
     __shared__ unsigned short s_item[MC_WPB_I][2 * MC_VN_CAP];  // the listed vertices: record lane | edge << 6; edge keys from the front, corner keys from the back
     __shared__ uint2 s_rc[MC_WPB_I][64];                         // per record of the chunk: {ix | iy << 16, iz}
     __shared__ uint2 s_rv[MC_WPB_I][64];                         // ... {first vertex, owned edges}
@@ -2990,12 +3052,12 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                     b[a1] -= d1;
                     b[a0] -= d0;
                     // (in that cell the vertex's lattice edge is edge mc_edge_of(ax, d0, d1): mc_resolve's rule)
-                    mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_trirow, cap_tris, b[0], b[1], b[2], v, mc_edge_of(ax, d0, d1), mine);
+                    mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_edgetri, cap_tris, b[0], b[1], b[2], v, mc_edge_of(ax, d0, d1), mine);
                 }
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 #pragma unroll
                 for (u32 step = 0; step < 4u; ++step) {
-                    if (j == step) mc_vn_add_cell(mine, tnrm, sx, sy, sz);
+                    mc_vn_add_cell_masked(j == step, mine, tnrm, sx, sy, sz);
                     if (step < 3u) {  // hand the sum to the next lane (row_shr:1; lanes 4 k .. 4 k + 3 sit in one DPP row)
                         const float tx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x111, 0xf, 0xf, false));
                         const float ty = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x111, 0xf, 0xf, false));
@@ -3032,7 +3094,7 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                     for (int dy = -1; dy <= (ax == 1 ? 1 : 0); ++dy)
                         for (int dx = -1; dx <= (ax == 0 ? 1 : 0); ++dx) {
                             McVnCell cc;
-                            mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_trirow, cap_tris, bx + dx, by + dy, bz + dz, v, -1, cc);
+                            mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_edgetri, cap_tris, bx + dx, by + dy, bz + dz, v, -1, cc);
                             mc_vn_add_cell(cc, tnrm, sx, sy, sz);
                         }
                 if ((u64)v < nverts) {
