@@ -2970,6 +2970,100 @@ __device__ __forceinline__ void mc_vn_add_cell_masked(bool on, const McVnCell& c
         }
     }
 }
+// The four cells around a lattice edge, ALL ON ONE LANE (round 4): lane = vertex, the loads of a level issued together for the
+// four cells (eight, sixteen, eight loads: the chain is three round trips per 64 vertices), no divergent branch but the rare
+// long segment.  The round-3 form put the four cells on four lanes -- 16 vertices per round, the sum handed from lane to lane
+// -- which is the same latency per vertex and four times the instructions, and instructions are what bounds the kernel.
+// qx / qy / qz: the cells in sweep order; me: the vertex's lattice edge as an edge of each cell (mc_resolve's rule).
+__device__ __forceinline__ void mc_vn_cells4(const McParams& p, const u32* __restrict__ recs, const uint2* __restrict__ segcb,
+                                             const u32* __restrict__ segtri, const float4* __restrict__ tnrm, const u8* s_edgetri, u64 cap_tris,
+                                             const int (&qx)[4], const int (&qy)[4], const int (&qz)[4], const int (&me)[4], bool act,
+                                             McVnCell (&out)[4]) {
+    bool in[4];
+    u32 seg[4], st[4], want[4];
+    uint2 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        in[j] = act && qx[j] >= 0 && qy[j] >= 0 && qx[j] < p.n1 && qy[j] < p.n1 && qz[j] >= p.z_begin && qz[j] < p.z_begin + p.nz;
+        seg[j] = in[j] ? (u32)(((qz[j] - p.z_begin) * p.n1 + qy[j]) * p.nchunk + (qx[j] >> 8)) : 0u;  // (segment 0 stands in: a valid address)
+        want[j] = (u32)(qx[j] & 255);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cb[j] = segcb[seg[j]];
+        st[j] = segtri[seg[j]];
+    }
+    asm volatile("" : "+v"(cb[0].x), "+v"(cb[0].y), "+v"(cb[1].x), "+v"(cb[1].y), "+v"(cb[2].x), "+v"(cb[2].y), "+v"(cb[3].x), "+v"(cb[3].y));
+    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
+    u32 n[4], r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        n[j] = in[j] ? cb[j].x >> 16 : 0u;
+        const u32 base = n[j] ? cb[j].y : 0u;  // (record 0 stands in; the buffer has slack behind its last record)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[j][i] = recs[base + (u32)i];
+    }
+    asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(r[1][3]));
+    asm volatile("" : "+v"(r[2][0]), "+v"(r[2][1]), "+v"(r[2][2]), "+v"(r[2][3]), "+v"(r[3][0]), "+v"(r[3][1]), "+v"(r[3][2]), "+v"(r[3][3]));
+    u32 rec[4];
+    bool found[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 w = want[j];
+        rec[j] = (r[j][0] & 0xFFu) == w ? r[j][0] : (n[j] > 1u && (r[j][1] & 0xFFu) == w) ? r[j][1] : (n[j] > 2u && (r[j][2] & 0xFFu) == w) ? r[j][2] : r[j][3];
+        found[j] = n[j] >= 1u && n[j] <= 4u && ((r[j][0] & 0xFFu) == w || (n[j] > 1u && (r[j][1] & 0xFFu) == w) || (n[j] > 2u && (r[j][2] & 0xFFu) == w) ||
+                                                (n[j] > 3u && (r[j][3] & 0xFFu) == w));
+    }
+    if (__ballot(n[0] > 4u || n[1] > 4u || n[2] > 4u || n[3] > 4u)) {  // (wave-uniform) a segment of more than four records: searched
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n[j] > 4u) {
+                u32 lo = cb[j].y, m = n[j];
+                while (m > 1u) {  // lower bound
+                    const u32 half = m >> 1;
+                    if ((recs[lo + half - 1u] & 0xFFu) < want[j]) {
+                        lo += half;
+                        m -= half;
+                    } else {
+                        m = half;
+                    }
+                }
+                rec[j] = recs[lo];
+                found[j] = (rec[j] & 0xFFu) == want[j];
+            }
+    }
+    u32 hm[4], t0[4], ta[4], tb[4], rest[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 nt = (rec[j] >> 17) & 7u, code = (rec[j] >> 8) & 0xFFu;
+        t0[j] = st[j] + (rec[j] >> 20);
+        u32 h = s_edgetri[(((rec[j] >> 16) & 1u) ? 255u - code : code) * 12u + (u32)me[j]];  // marching.cpp:542-547
+        const u64 room = cap_tris > (u64)t0[j] ? cap_tris - (u64)t0[j] : 0ull;  // triangles beyond the buffer's capacity do not exist
+        if (room < 5ull) h &= (1u << (u32)room) - 1u;
+        h &= (1u << nt) - 1u;  // (seed mode: a record outside the seed's component keeps its code and has no triangles)
+        hm[j] = found[j] ? h : 0u;
+        rest[j] = hm[j] & (hm[j] - 1u);
+        ta[j] = hm[j] ? (u32)__builtin_ctz(hm[j]) : 0u;
+        tb[j] = rest[j] ? (u32)__builtin_ctz(rest[j]) : 0u;
+    }
+    float4 fa[4], fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        fa[j] = tnrm[hm[j] ? t0[j] + ta[j] : 0u];
+        fb[j] = tnrm[rest[j] ? t0[j] + tb[j] : 0u];
+    }
+    asm volatile("" : "+v"(fa[0].x), "+v"(fa[0].w), "+v"(fb[0].x), "+v"(fb[0].w), "+v"(fa[1].x), "+v"(fa[1].w), "+v"(fb[1].x), "+v"(fb[1].w));
+    asm volatile("" : "+v"(fa[2].x), "+v"(fa[2].w), "+v"(fb[2].x), "+v"(fb[2].w), "+v"(fa[3].x), "+v"(fa[3].w), "+v"(fb[3].x), "+v"(fb[3].w));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (a triangle touches an edge once: hit count 1 where the triangle exists and is not degenerate)
+        out[j].a = make_float4(fa[j].x, fa[j].y, fa[j].z, __builtin_bit_cast(float, (hm[j] && fa[j].w != 0.0f) ? 1u : 0u));
+        out[j].b = make_float4(fb[j].x, fb[j].y, fb[j].z, __builtin_bit_cast(float, (rest[j] && fb[j].w != 0.0f) ? 1u : 0u));
+        out[j].more = rest[j] & (rest[j] - 1u);
+        out[j].hp = (hm[j] & 1u) | ((hm[j] & 2u) << 1) | ((hm[j] & 4u) << 2) | ((hm[j] & 8u) << 3) | ((hm[j] & 16u) << 4);
+        out[j].t0 = t0[j];
+    }
+}
 extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McParams* __restrict__ P, const u32* __restrict__ recs,
                                                                         const uint2* __restrict__ segcb, const uint2* __restrict__ grpoff,
                                                                         const u32* __restrict__ recown, const u32* __restrict__ recvb,
@@ -3028,48 +3122,37 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---- vertices whose key is their lattice edge: 16 per round, lane = 4 * vertex + cell (cells in sweep order).  The
-            // sum travels through the four lanes of a vertex (DPP, one lane to the right per step): lane j adds its cell's
-            // triangles to what the cells before it have summed -- the reference's additions in the reference's order, no LDS
-            for (u32 k0 = 0; k0 < NE; k0 += 16u) {
-                const u32 k = k0 + ((u32)lane >> 2), j = (u32)lane & 3u;
-                McVnCell mine;
-                mine.a = mine.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                mine.more = mine.hp = mine.t0 = 0u;
-                u32 v = 0xFFFFFFFFu;
-                if (k < NE) {
-                    const u32 it = item[k];
-                    const int e = (int)(it >> 6);
-                    const uint2 c = rc[it & 63u];
-                    const uint2 o = rv[it & 63u];
-                    v = o.x + (u32)__builtin_popcount(o.y & ((1u << e) - 1u));
-                    const int ax = edge_axis(e);
-                    // lower end of the lattice edge; the cells around it: offsets -1 / 0 on the two other axes, the slower axis first
-                    int b[3] = {(int)(c.x & 0xFFFFu) + (int)((MC_EDGE_OX >> e) & 1u), (int)(c.x >> 16) + (int)((MC_EDGE_OY >> e) & 1u),
-                                (int)c.y + (int)((MC_EDGE_OZ >> e) & 1u)};
-                    const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
-                    const int d1 = 1 - (int)(j >> 1), d0 = 1 - (int)(j & 1u);
-                    b[a1] -= d1;
-                    b[a0] -= d0;
-                    // (in that cell the vertex's lattice edge is edge mc_edge_of(ax, d0, d1): mc_resolve's rule)
-                    mc_vn_cell(p, recs, segcb, segtri, tlist, tnrm, s_edgetri, cap_tris, b[0], b[1], b[2], v, mc_edge_of(ax, d0, d1), mine);
+            // ---- vertices whose key is their lattice edge: 64 per round, lane = vertex; its four cells in sweep order on the one
+            // lane (mc_vn_cells4), their triangles added in that order -- the reference's additions in the reference's order
+            for (u32 k0 = 0; k0 < NE; k0 += 64u) {
+                const u32 k = k0 + (u32)lane;
+                const bool act = k < NE;
+                const u32 it = act ? item[k] : 0u;
+                const int e = (int)(it >> 6);
+                const uint2 c = rc[it & 63u];
+                const uint2 o = rv[it & 63u];
+                const u32 v = o.x + (u32)__builtin_popcount(o.y & ((1u << e) - 1u));
+                const int ax = edge_axis(e);
+                // lower end of the lattice edge; the cells around it: offsets -1 / 0 on the two other axes (a0 = the faster of the
+                // two, a1 the slower), the slower axis first.  Written per axis with constant offsets: a private array indexed by
+                // a0 / a1 would live in scratch
+                const int bx = (int)(c.x & 0xFFFFu) + (int)((MC_EDGE_OX >> e) & 1u), by = (int)(c.x >> 16) + (int)((MC_EDGE_OY >> e) & 1u),
+                          bz = (int)c.y + (int)((MC_EDGE_OZ >> e) & 1u);
+                int qx[4], qy[4], qz[4], me[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d1 = 1 - (j >> 1), d0 = 1 - (j & 1);
+                    qx[j] = bx - (ax != 0 ? d0 : 0);                           // a0 is x unless the edge runs along x
+                    qy[j] = by - (ax == 0 ? d0 : 0) - (ax == 2 ? d1 : 0);      // y: a0 for an x edge, a1 for a z edge
+                    qz[j] = bz - (ax != 2 ? d1 : 0);                           // a1 is z unless the edge runs along z
+                    me[j] = mc_edge_of(ax, d0, d1);  // (in that cell the vertex's lattice edge is this edge: mc_resolve's rule)
                 }
+                McVnCell cell[4];
+                mc_vn_cells4(p, recs, segcb, segtri, tnrm, s_edgetri, cap_tris, qx, qy, qz, me, act, cell);
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 #pragma unroll
-                for (u32 step = 0; step < 4u; ++step) {
-                    mc_vn_add_cell_masked(j == step, mine, tnrm, sx, sy, sz);
-                    if (step < 3u) {  // hand the sum to the next lane (row_shr:1; lanes 4 k .. 4 k + 3 sit in one DPP row)
-                        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x111, 0xf, 0xf, false));
-                        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x111, 0xf, 0xf, false));
-                        const float tz = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sz), 0x111, 0xf, 0xf, false));
-                        if (j == step + 1u) {
-                            sx = tx;
-                            sy = ty;
-                            sz = tz;
-                        }
-                    }
-                }
-                if (j == 3u && k < NE && (u64)v < nverts) {
+                for (int j = 0; j < 4; ++j) mc_vn_add_cell_masked(act, cell[j], tnrm, sx, sy, sz);
+                if (act && (u64)v < nverts) {
                     const float d = (sx * sx + sy * sy) + sz * sz;
                     const float inv = 1.0f / __builtin_sqrtf(d);  // glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt = 1 / sqrt
                     vnrm[3ull * v] = sx * inv;
