@@ -2586,29 +2586,67 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vmark(const McPar
                                                                       u64* __restrict__ grpv) {
     __shared__ u32 s_cnt[MC_WPB_I];  // vertices owned by the records of each of the workgroup's groups
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = 0u;  // (in front of the macro's barrier)
+    // Round 4: one lane per (record, crossed edge) PAIR, listed in LDS like mc_emit_direct's triangles.  With a lane per
+    // record a cell's edges were resolved one after the other -- 4.2 on average, as many steps as the wave's busiest cell has
+    // (6-7) -- and the kernel is bound by its vector instructions (87 M, SQ_ACTIVE_INST_VALU = 0.14 of its 0.16 ms per SIMD).
+    __shared__ unsigned short s_pair[MC_WPB_I][64 * 12];  // record lane | edge << 6
+    __shared__ uint2 s_cell[MC_WPB_I][64];                // per record of the chunk: {ix | iy << 16, iz}
+    __shared__ float s_c6[MC_WPB_I][6][64];               // ... its six lattice coordinates {x0, x1, y0, y1, z0, z1}
+    __shared__ u32 s_acc[MC_WPB_I][64];                   // ... owned edges | corner-keyed edges << 16, OR-ed in by the pair lanes
+    const int wme = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     MC_GROUP_LDS_SHARED_BEGIN
     {
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        u32 ownm = 0;
-        if (valid && !((rec >> 17) & 7u)) recown[ridx] = 0u;  // seed mode: a cell outside the seed's component (no triangles left)
-        if (valid && ((rec >> 17) & 7u)) {
-            u32 m = crossed_edges((rec >> 8) & 0xFFu), cornm = 0;
-            // the cell's six lattice coordinates, once and together, for the snap test of every crossed edge (five loads and a
-            // memory round trip PER EDGE otherwise: the edge loop's iterations do not overlap)
-            float c6[6] = {p.axis[ix], p.axis[ix + 1], p.axis[iy], p.axis[iy + 1], p.axis[iz], p.axis[iz + 1]};
+        const bool live = valid && ((rec >> 17) & 7u);
+        if (valid && !live) recown[ridx] = 0u;  // seed mode: a cell outside the seed's component (no triangles left)
+        unsigned short* pair = s_pair[wme];
+        u32 m = live ? crossed_edges((rec >> 8) & 0xFFu) : 0u;
+        {
+            // the cell's six lattice coordinates, once and together, for the snap test of every crossed edge
+            const int jx = live ? ix : 0, jy = live ? iy : 0, jz = live ? iz : 0;
+            float c6[6] = {p.axis[jx], p.axis[jx + 1], p.axis[jy], p.axis[jy + 1], p.axis[jz], p.axis[jz + 1]};
             asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
-            while (m) {
-                const int e = __builtin_ctz(m);
-                m &= m - 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the pairs of the chunk before have been read)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s_c6[wme][i][lane] = c6[i];
+        }
+        s_cell[wme][lane] = make_uint2((u32)ix | ((u32)iy << 16), (u32)iz);
+        s_acc[wme][lane] = 0u;
+        const u32 cnt = (u32)__builtin_popcount(m), incl = wave_inclusive_scan(cnt);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        for (u32 j = incl - cnt; m; ++j) {
+            const u32 e = (u32)__builtin_ctz(m);
+            m &= m - 1u;
+            pair[j] = (unsigned short)((u32)lane | (e << 6));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 k0 = 0; k0 < total; k0 += 64u) {
+            const u32 k = k0 + (u32)lane;
+            if (k < total) {
+                const u32 it = pair[k];
+                const u32 rl = it & 63u;
+                const int e = (int)(it >> 6);
+                const uint2 cc = s_cell[wme][rl];
+                const int cx = (int)(cc.x & 0xFFFFu), cy = (int)(cc.x >> 16), cz = (int)cc.y;
+                const float c6[6] = {s_c6[wme][0][rl], s_c6[wme][1][rl], s_c6[wme][2][rl], s_c6[wme][3][rl], s_c6[wme][4][rl], s_c6[wme][5][rl]};
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner, false, c6);
-                if (qx == ix && qy == iy && qz == iz && qe == e) ownm |= 1u << e;
-                if (corner) cornm |= 1u << e;
+                mc_resolve(p, codes, recs, segcb, cx, cy, cz, e, qx, qy, qz, qe, corner, false, c6);
+                const u32 bits = ((qx == cx && qy == cy && qz == cz && qe == e) ? 1u << e : 0u) | (corner ? 0x10000u << e : 0u);
+                if (bits) __hip_atomic_fetch_or(&s_acc[wme][rl], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-            recown[ridx] = ownm | (cornm << 16);  // bits 0..11: owned edges; 16..27: the crossed edges whose key is a lattice corner
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u32 ownm = 0;
+        if (live) {
+            const u32 acc = s_acc[wme][lane];
+            ownm = acc & 0xFFFu;
+            recown[ridx] = acc;  // bits 0..11: owned edges; 16..27: the crossed edges whose key is a lattice corner
         }
         const u32 sum = wave_inclusive_scan((u32)__builtin_popcount(ownm));
         if (lane == 63 && sum) __hip_atomic_fetch_add(&s_cnt[wv], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
