@@ -2732,7 +2732,14 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
                                                                        const u32* __restrict__ recvb, u32* __restrict__ tlist, u64 cap_tris,
                                                                        u32* __restrict__ segtri) {
     __shared__ u32 s_eidx[MC_WPB_I][64 * 13];  // per lane: the vertex index of each of its 12 edges (stride 13: no bank conflicts)
-    u32* eidx = s_eidx[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))] + 13 * (threadIdx.x & 63);
+    // Round 4: one lane per (record, crossed edge) PAIR.  With a lane per record the edges of a cell were walked one after the
+    // other -- 4.2 on average, as many steps as the wave's busiest cell has (6-7), every step a chain of three dependent
+    // look-ups (the owner's segment, its record, its vertex numbers).  The pairs are listed in LDS (like mc_emit_direct's
+    // triangles) and taken 64 at a time; a pair's cell comes from its record's lane by ds_bpermute (no LDS of its own: LDS is
+    // what limits the waves per CU here, and the kernel needs them).
+    __shared__ unsigned short s_pair[MC_WPB_I][64 * 12];  // record lane | edge << 6
+    const int wme = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    u32* eidx = s_eidx[wme] + 13 * (threadIdx.x & 63);
     MC_GROUP_LDS_SHARED_BEGIN
     // lane = segment: its first triangle, for mc_vnormal (a record's first triangle = its segment's + the record's prefix);
     // written with the group's first chunk
@@ -2742,34 +2749,60 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vindex(const McPa
         u32 ridx, rec, gtri0;
         int ix, iy, iz;
         const bool valid = mc_group_record(g, recs, r0 + (u32)lane, ridx, rec, ix, iy, iz, gtri0);
-        if (valid && ((rec >> 17) & 7u)) {
-            const u32 code = (rec >> 8) & 0xFFu;
-            const u32 myrow = recown[ridx];
-            const u32 myown = myrow & 0xFFFu, myvb = recvb[ridx];
-            u32 m = crossed_edges(code);
-            while (m) {
-                const int e = __builtin_ctz(m);
-                m &= m - 1u;
+        const bool live = valid && ((rec >> 17) & 7u);
+        const u32 code = (rec >> 8) & 0xFFu;
+        u32 myrow = live ? recown[ridx] : 0u, myvb = live ? recvb[ridx] : 0u;
+        asm volatile("" : "+v"(myrow), "+v"(myvb));  // (one level)
+        unsigned short* pair = s_pair[wme];
+        const u32 cxy = (u32)ix | ((u32)iy << 16);
+        u32 m = live ? crossed_edges(code) : 0u;
+        const u32 cnt = (u32)__builtin_popcount(m), incl = wave_inclusive_scan(cnt);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the pairs of the chunk before have been read)
+        __builtin_amdgcn_wave_barrier();
+        for (u32 j = incl - cnt; m; ++j) {
+            const u32 e = (u32)__builtin_ctz(m);
+            m &= m - 1u;
+            pair[j] = (unsigned short)((u32)lane | (e << 6));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 k0 = 0; k0 < total; k0 += 64u) {
+            const u32 k = k0 + (u32)lane;
+            const bool act = k < total;
+            const u32 it = act ? pair[k] : 0u;
+            const int rl = (int)(it & 63u);
+            const int e = (int)(it >> 6);
+            // (the shuffles outside any lane-dependent control flow: a ds_bpermute reads 0 from a lane that is switched off)
+            const u32 pxy = (u32)__shfl((int)cxy, rl, 64), pz = (u32)__shfl(iz, rl, 64);
+            const u32 prow = (u32)__shfl((int)myrow, rl, 64), pvb = (u32)__shfl((int)myvb, rl, 64);
+            if (act) {
+                const int cx = (int)(pxy & 0xFFFFu), cy = (int)(pxy >> 16), cz = (int)pz;
                 int qx, qy, qz, qe;
                 bool corner;
-                mc_resolve(p, codes, recs, segcb, ix, iy, iz, e, qx, qy, qz, qe, corner, ((myrow >> (16 + e)) & 1u) == 0u);
-                u32 o = myown, vb = myvb;
+                mc_resolve(p, codes, recs, segcb, cx, cy, cz, e, qx, qy, qz, qe, corner, ((prow >> (16 + e)) & 1u) == 0u);
+                u32 o = prow & 0xFFFu, vb = pvb, idx;
                 if (qz < p.z_begin) {
                     // MC_FLAG_SEAM: the owner is a cell of the layer below the swept range (the lower plane of the ghost layer):
                     // it has no record here and its vertex no index; only ghost cells meet this, and their triangles are
                     // never handed out
-                    eidx[e] = 0xFFFFFFFFu;
-                    continue;
+                    idx = 0xFFFFFFFFu;
+                } else {
+                    if (!(qx == cx && qy == cy && qz == cz)) {
+                        const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
+                        u32 oq = recown[q], vq = recvb[q];
+                        asm volatile("" : "+v"(oq), "+v"(vq));  // (one level)
+                        o = oq & 0xFFFu;
+                        vb = vq;
+                    }
+                    idx = vb + (u32)__builtin_popcount(o & ((1u << qe) - 1u));
                 }
-                if (!(qx == ix && qy == iy && qz == iz)) {
-                    const u32 q = mc_find_record(p, recs, segcb, qx, qy, qz);
-                    u32 oq = recown[q], vq = recvb[q];
-                    asm volatile("" : "+v"(oq), "+v"(vq));  // (one level)
-                    o = oq & 0xFFFu;
-                    vb = vq;
-                }
-                eidx[e] = vb + (u32)__builtin_popcount(o & ((1u << qe) - 1u));
+                s_eidx[wme][13u * (u32)rl + (u32)e] = idx;
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
             const u32 row = ((rec >> 16) & 1u) ? 255u - code : code;  // marching.cpp:542-547
             const u64 tr = c_tri_row[row];
             const u32 nt = (rec >> 17) & 7u;
