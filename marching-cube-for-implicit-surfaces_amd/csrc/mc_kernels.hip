@@ -3141,7 +3141,8 @@ extern "C" __global__ __launch_bounds__(64 * MC_WPB_I) void mc_vnormal(const McP
                                                                         const u32* __restrict__ segtri, const u32* __restrict__ tlist,
                                                                         const float4* __restrict__ tnrm, float* __restrict__ vnrm, u64 nverts,
                                                                         u64 cap_tris) {
-    // (LDS is what limits the waves per CU here, and the kernel lives on them: 71 % of its wave-cycles are waits for loads)
+    // (round 4's counters: 95 M vector instructions, half of the kernel's time per SIMD -- 223 M and three quarters before a
+    // vertex's four cells moved onto one lane --, the rest the three round trips of a look-up per 64 vertices)
     // per (case-table row, edge): bit t = triangle t of the row has a corner on that edge (mc_vn_cell; c_edgetri: made at compile
     // time from marching_lookup.h:64-320's rows); filled in front of the macro's barrier
     __shared__ u32 s_edgetri32[256 * 12 / 4];
