@@ -470,7 +470,7 @@ __device__ __forceinline__ void lds_union(u32* lab, u32 a, u32 b) {
     }
 }
 
-#define CC_WIN 1024u  // records of a group labelled together in LDS (a group of the 1025^3 sphere has ~60, of the gyroid ~250)
+#define CC_WIN 512u  // records of a group labelled together in LDS (a group of the 1025^3 sphere has ~60, of the gyroid ~250; a power of two)
 
 // what the two kernels below share: the group's segments (lane = segment), their record offsets inside the group
 // (s_off[0..64]) and first record indices, in LDS; returns the group's record count
